@@ -1,0 +1,289 @@
+// rt_device.h — device-resident scene layout and the per-ray device functions shared by every
+// kernel of librustracer_amd (gfx950 only).
+//
+// Every function states the reference function whose arithmetic it reproduces (paths relative to
+// /root/reference).  All f32 expressions keep the reference's operand order and associativity;
+// the translation unit is compiled with -ffp-contract=off so no mul/add pair is fused.
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/rt_strict_math.h"
+#include "../../include/rustracer_amd.h"
+
+#pragma clang fp contract(off)
+
+namespace rtd {
+
+// ---------------------------------------------------------------------------------------------
+// HBM layout of the flattened World
+// ---------------------------------------------------------------------------------------------
+
+// One shape = 160 B, 16-B aligned, read with wave-uniform (scalar) loads in the closest-hit scan
+// and with per-lane vector loads once per ray for the winner.
+struct __attribute__((aligned(16))) DShape {
+    float inv[16];      // Transformation.invm, row-major
+    float m[16];        // Transformation.m, row-major
+    uint32_t kind;      // RT_SHAPE_*
+    uint32_t material;  // index into DMaterial table
+    uint32_t needs_uv;  // 1 if either pigment of the material reads (u,v)
+    uint32_t pad[5];
+};
+static_assert(sizeof(DShape) == 160, "DShape layout");
+
+struct DPigment {
+    uint32_t kind;      // RT_PIGMENT_*
+    float c1[3];
+    float c2[3];
+    uint32_t steps;
+    uint32_t tex_w, tex_h;
+    uint32_t tex_off;   // float offset of the texture in the texel pool
+    uint32_t pad;
+};
+static_assert(sizeof(DPigment) == 48, "DPigment layout");
+
+struct __attribute__((aligned(16))) DMaterial {
+    uint32_t brdf;      // RT_BRDF_*
+    uint32_t pad[3];
+    DPigment brdf_pigment;
+    DPigment emitted;
+};
+static_assert(sizeof(DMaterial) == 112, "DMaterial layout");
+
+struct Vec3 { float x, y, z; };
+
+// ---------------------------------------------------------------------------------------------
+// PCG (src/random.rs)
+// ---------------------------------------------------------------------------------------------
+#define RT_PCG_MULT 6364136223846793005ULL
+
+// Pcg::random output permutation of the OLD state (random.rs:40-42).
+__device__ __forceinline__ uint32_t pcg_output(uint64_t old_state) {
+    const uint32_t xor_shifted = (uint32_t)(((old_state >> 18) ^ old_state) >> 27);
+    const uint32_t rot = (uint32_t)(old_state >> 59);
+    return (xor_shifted >> rot) | (xor_shifted << ((0u - rot) & 31u));
+}
+// Pcg::random (random.rs:37-43)
+__device__ __forceinline__ uint32_t pcg_random(uint64_t& state, uint64_t inc) {
+    const uint64_t old_state = state;
+    state = old_state * RT_PCG_MULT + inc;
+    return pcg_output(old_state);
+}
+// Pcg::random_float (random.rs:46-48): r as f32 / 2^32 == rn(r) * 2^-32 exactly.
+__device__ __forceinline__ float pcg_random_float(uint64_t& state, uint64_t inc) {
+    return (float)pcg_random(state, inc) * 2.3283064365386962890625e-10f;
+}
+// Pcg::new (random.rs:26-34): state after the two warm-up draws.
+__device__ __forceinline__ void pcg_new(uint64_t init_state, uint64_t init_seq, uint64_t& state, uint64_t& inc) {
+    inc = (init_seq << 1) | 1ULL;
+    state = 0;
+    (void)pcg_random(state, inc);
+    state += init_state;
+    (void)pcg_random(state, inc);
+}
+
+// ---------------------------------------------------------------------------------------------
+// Transformation * {Point, Vector, Normal} (src/transformation.rs:133-195)
+// ---------------------------------------------------------------------------------------------
+
+// T*Point with matrix rows M[0..15]; AFFINE promises M[12..15] == {0,0,0,1} bit-exactly, in which
+// case w == 1 for every finite point and the reference takes the no-divide branch.
+template <bool AFFINE>
+__device__ __forceinline__ Vec3 xform_point(const float* __restrict__ M, float x, float y, float z) {
+    Vec3 r;
+    r.x = M[0] * x + M[1] * y + M[2] * z + M[3];
+    r.y = M[4] * x + M[5] * y + M[6] * z + M[7];
+    r.z = M[8] * x + M[9] * y + M[10] * z + M[11];
+    if (!AFFINE) {
+        const float w = x * M[12] + y * M[13] + z * M[14] + M[15];
+        if (!(w == 1.0f)) {
+            r.x = r.x / w;
+            r.y = r.y / w;
+            r.z = r.z / w;
+        }
+    }
+    return r;
+}
+__device__ __forceinline__ Vec3 xform_vector(const float* __restrict__ M, float x, float y, float z) {
+    Vec3 r;
+    r.x = M[0] * x + M[1] * y + M[2] * z;
+    r.y = M[4] * x + M[5] * y + M[6] * z;
+    r.z = M[8] * x + M[9] * y + M[10] * z;
+    return r;
+}
+// T*Normal: inverse matrix transposed (transformation.rs:145-161); I = Transformation.invm.
+__device__ __forceinline__ Vec3 xform_normal(const float* __restrict__ I, float x, float y, float z) {
+    Vec3 r;
+    r.x = I[0] * x + I[4] * y + I[8] * z;
+    r.y = I[1] * x + I[5] * y + I[9] * z;
+    r.z = I[2] * x + I[6] * y + I[10] * z;
+    return r;
+}
+
+// ---------------------------------------------------------------------------------------------
+// Shape::ray_intersection, candidate part: only `t` is produced here; the HitRecord of the final
+// winner is built once by hit_record() below (result-identical: World keeps one record).
+// ---------------------------------------------------------------------------------------------
+
+// Sphere::ray_intersection up to first_hit_t (src/shape.rs:112-133).
+__device__ __forceinline__ bool sphere_t(Vec3 o, Vec3 d, float tmin, float tmax, float& t_out) {
+    const float a = d.x * d.x + d.y * d.y + d.z * d.z;
+    const float b = 2.0f * (o.x * d.x + o.y * d.y + o.z * d.z);
+    const float c = (o.x * o.x + o.y * o.y + o.z * o.z) - 1.0f;
+    const float delta = b * b - 4.0f * a * c;
+    if (delta <= 0.0f) return false;
+    const float sqrt_delta = __builtin_sqrtf(delta);
+    const float a2 = 2.0f * a;
+    const float t1 = (-b - sqrt_delta) / a2;
+    if ((t1 > tmin) && (t1 < tmax)) {
+        t_out = t1;
+        return true;
+    }
+    const float t2 = (-b + sqrt_delta) / a2;
+    if ((t2 > tmin) && (t2 < tmax)) {
+        t_out = t2;
+        return true;
+    }
+    return false;
+}
+
+// Plane::ray_intersection up to t (src/shape.rs:196-204).
+__device__ __forceinline__ bool plane_t(Vec3 o, Vec3 d, float tmin, float tmax, float& t_out) {
+    if (__builtin_fabsf(d.z) < 1e-5f) return false;
+    const float t = -o.z / d.z;
+    if ((t <= tmin) || (t >= tmax)) return false;
+    t_out = t;
+    return true;
+}
+
+struct HitRec {
+    Vec3 world_point;
+    Vec3 normal;
+    float u, v;
+};
+
+// The HitRecord fields of the winning shape (src/shape.rs:134-142, :205-213), with
+// sphere_normal (:88-95), sphere_point_to_uv (:101-108), plane_normal (:175-182),
+// plane_point_to_uv (:187-192).  S points at the winner's DShape (per-lane address).
+template <bool AFFINE>
+__device__ __forceinline__ HitRec hit_record(const DShape* __restrict__ S, Vec3 ro, Vec3 rd, float t, bool want_uv) {
+    HitRec h;
+    const Vec3 o = xform_point<AFFINE>(S->inv, ro.x, ro.y, ro.z);
+    const Vec3 d = xform_vector(S->inv, rd.x, rd.y, rd.z);
+    // inv_ray.at(t) (src/ray.rs:26-28)
+    const float hx = o.x + d.x * t, hy = o.y + d.y * t, hz = o.z + d.z * t;
+    h.world_point = xform_point<AFFINE>(S->m, hx, hy, hz);
+    h.u = 0.0f;
+    h.v = 0.0f;
+    if (S->kind == RT_SHAPE_SPHERE) {
+        const float dp = hx * d.x + hy * d.y + hz * d.z;
+        float nx = hx, ny = hy, nz = hz;
+        if (!(dp < 0.0f)) { nx = -nx; ny = -ny; nz = -nz; }
+        h.normal = xform_normal(S->inv, nx, ny, nz);
+        if (want_uv) {
+            float u = rt_atan2f(hy, hx) / 6.2831854820251465f;  // 2.0 * PI in f32
+            const float v = rt_acosf(hz) / 3.1415927410125732f; // PI in f32
+            if (u < 0.0f) u += 1.0f;
+            h.u = u;
+            h.v = v;
+        }
+    } else {
+        const float dp = 0.0f * d.x + 0.0f * d.y + 1.0f * d.z;
+        float nx = 0.0f, ny = 0.0f, nz = 1.0f;
+        if (!(dp < 0.0f)) { nx = -0.0f; ny = -0.0f; nz = -1.0f; }
+        h.normal = xform_normal(S->inv, nx, ny, nz);
+        if (want_uv) {
+            h.u = hx - __builtin_floorf(hx);
+            h.v = hy - __builtin_floorf(hy);
+        }
+    }
+    return h;
+}
+
+// World::ray_intersection (src/world.rs:32-50): linear scan in insertion order, strict `<`, so the
+// earliest shape wins ties; the first hit is taken unconditionally (even t = NaN).
+// `shapes` and `n_shapes` are wave-uniform, so the table is read through scalar loads.
+template <bool AFFINE>
+__device__ __forceinline__ int closest_hit(const DShape* __restrict__ shapes, uint32_t n_shapes, Vec3 ro, Vec3 rd,
+                                           float tmin, float tmax, float& best_t) {
+    int best = -1;
+    best_t = 0.0f;
+    for (uint32_t i = 0; i < n_shapes; ++i) {
+        const DShape* __restrict__ S = shapes + i;
+        const Vec3 o = xform_point<AFFINE>(S->inv, ro.x, ro.y, ro.z);
+        const Vec3 d = xform_vector(S->inv, rd.x, rd.y, rd.z);
+        float t = 0.0f;
+        bool hit;
+        if (S->kind == RT_SHAPE_SPHERE) hit = sphere_t(o, d, tmin, tmax, t);
+        else hit = plane_t(o, d, tmin, tmax, t);
+        if (hit && (best < 0 || t < best_t)) {
+            best = (int)i;
+            best_t = t;
+        }
+    }
+    return best;
+}
+
+// ---------------------------------------------------------------------------------------------
+// Pigment::get_color (src/material.rs:32-36, :54-70, :86-96, :106-115)
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ Vec3 pigment_color(const DPigment* __restrict__ p, const float* __restrict__ texels, float u, float v) {
+    Vec3 c;
+    const uint32_t kind = p->kind;
+    if (kind == RT_PIGMENT_UNIFORM) {
+        c.x = p->c1[0]; c.y = p->c1[1]; c.z = p->c1[2];
+    } else if (kind == RT_PIGMENT_CHECKERED) {
+        const float steps = (float)p->steps;
+        const uint32_t int_u = rt_f32_to_u32_sat(__builtin_floorf(u * steps));
+        const uint32_t int_v = rt_f32_to_u32_sat(__builtin_floorf(v * steps));
+        if ((int_u % 2u) == (int_v % 2u)) { c.x = p->c1[0]; c.y = p->c1[1]; c.z = p->c1[2]; }
+        else { c.x = p->c2[0]; c.y = p->c2[1]; c.z = p->c2[2]; }
+    } else {
+        const uint32_t w = p->tex_w, h = p->tex_h;
+        uint32_t col = rt_f32_to_u32_sat(u * (float)w);
+        uint32_t row = rt_f32_to_u32_sat(v * (float)h);
+        if (col >= w) col = w - 1;
+        if (row >= h) row = h - 1;
+        const float* px = texels + p->tex_off + 3ull * ((uint64_t)row * w + col);
+        c.x = px[0]; c.y = px[1]; c.z = px[2];
+    }
+    return c;
+}
+
+// ---------------------------------------------------------------------------------------------
+// BRDF::scatter_ray (src/material.rs:161-186, :225-246) + create_onb_from_z (src/normal.rs:143-158)
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ Vec3 diffuse_scatter_dir(float rf0, float rf1, Vec3 n) {
+    const float sign = __builtin_copysignf(1.0f, n.z);
+    const float a = -1.0f / (sign + n.z);
+    const float b = n.x * n.y * a;
+    const float e1x = 1.0f + sign * n.x * n.x * a, e1y = sign * b, e1z = -sign * n.x;
+    const float e2x = b, e2y = sign + n.y * n.y * a, e2z = -n.y;
+    const float cos_theta = __builtin_sqrtf(rf0);
+    const float sin_theta = __builtin_sqrtf(1.0f - rf0);
+    const float phi = 6.2831854820251465f * rf1;  // (2.0 * PI) * pcg.1
+    float sn, cs;
+    rt_sincosf(phi, &sn, &cs);
+    Vec3 d;
+    d.x = e1x * cs * cos_theta + e2x * sn * cos_theta + n.x * sin_theta;
+    d.y = e1y * cs * cos_theta + e2y * sn * cos_theta + n.y * sin_theta;
+    d.z = e1z * cs * cos_theta + e2z * sn * cos_theta + n.z * sin_theta;
+    return d;
+}
+
+__device__ __forceinline__ Vec3 specular_scatter_dir(Vec3 in, Vec3 n) {
+    // Vector::normalize = v * (1 / norm) (src/vector.rs:72-75)
+    const float inv_r = 1.0f / __builtin_sqrtf(in.x * in.x + in.y * in.y + in.z * in.z);
+    const float rx = in.x * inv_r, ry = in.y * inv_r, rz = in.z * inv_r;
+    const float inv_n = 1.0f / __builtin_sqrtf(n.x * n.x + n.y * n.y + n.z * n.z);
+    const float nx = n.x * inv_n, ny = n.y * inv_n, nz = n.z * inv_n;
+    const float dot_prod = nx * rx + ny * ry + nz * rz;
+    Vec3 d;
+    d.x = rx - nx * 2.0f * dot_prod;
+    d.y = ry - ny * 2.0f * dot_prod;
+    d.z = rz - nz * 2.0f * dot_prod;
+    return d;
+}
+
+}  // namespace rtd

@@ -1,0 +1,119 @@
+"""ctypes loader of oracle/liboracle.so — the CPU checker (test infrastructure only).
+
+Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg import this module.
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+from rustracer_amd import _abi
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ORACLE_DIR = os.path.join(ROOT, "oracle")
+ORACLE_SO = os.path.join(ORACLE_DIR, "liboracle.so")
+
+MATH_LIBM, MATH_STRICT = 0, 1
+_lib = None
+P = C.POINTER
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(ORACLE_SO):
+            subprocess.check_call(["make", "-C", ORACLE_DIR, "liboracle.so"])
+        h = C.CDLL(ORACLE_SO)
+        scene = [P(_abi.rt_shape), C.c_uint32, P(_abi.rt_material), C.c_uint32, P(_abi.rt_texture), C.c_uint32]
+        h.oracle_fire_all_rays.argtypes = scene + [P(_abi.rt_camera), P(_abi.rt_renderer), C.c_uint32, C.c_uint32,
+                                                   C.c_uint64, C.c_uint64, C.c_uint32, C.c_uint32, C.c_uint32,
+                                                   C.c_int, C.c_int, P(C.c_float), P(_abi.rt_stats)]
+        h.oracle_all_rays_seeds.argtypes = [C.c_uint32, C.c_uint32, C.c_uint64, C.c_uint64, C.c_uint32,
+                                            P(C.c_float), P(C.c_uint64)]
+        h.oracle_fire_ray.argtypes = [P(_abi.rt_camera), C.c_uint32, C.c_uint32, P(C.c_uint32), P(C.c_uint32),
+                                      P(C.c_float), P(C.c_float), C.c_uint64, P(_abi.rt_ray)]
+        h.oracle_camera_fire_ray.argtypes = [P(_abi.rt_camera), P(C.c_float), P(C.c_float), C.c_uint64, P(_abi.rt_ray)]
+        h.oracle_world_ray_intersection.argtypes = scene + [P(_abi.rt_ray), C.c_uint64, C.c_int, P(_abi.rt_hit)]
+        h.oracle_renderer_solve.argtypes = scene + [P(_abi.rt_renderer), P(_abi.rt_ray), P(_abi.rt_pcg), C.c_uint64,
+                                                    C.c_int, P(C.c_float)]
+        h.oracle_pcg_new.argtypes = [C.c_uint64, C.c_uint64, P(_abi.rt_pcg)]
+        h.oracle_pcg_random.argtypes = [P(C.c_uint64), P(C.c_uint64), C.c_uint64, C.c_uint32, P(C.c_uint32)]
+        h.oracle_pcg_random_float.argtypes = [P(_abi.rt_pcg), C.c_uint32, P(C.c_float)]
+        h.oracle_pigment_get_color.argtypes = [P(_abi.rt_pigment), P(_abi.rt_texture), C.c_uint32, P(C.c_float),
+                                               C.c_uint64, P(C.c_float)]
+        h.oracle_scatter_ray.argtypes = [C.c_uint32, C.c_float, C.c_float, P(C.c_float), P(C.c_float), P(C.c_float),
+                                         C.c_uint32, C.c_int, P(_abi.rt_ray)]
+        h.oracle_create_onb_from_z.argtypes = [P(C.c_float), P(C.c_float)]
+        h.oracle_transform.argtypes = [P(C.c_float), P(C.c_float), C.c_int, P(C.c_float), P(C.c_float)]
+        h.oracle_math_eval.argtypes = [C.c_int, C.c_int, P(C.c_float), P(C.c_float), C.c_uint64, P(C.c_float)]
+        for name in ("oracle_fire_all_rays", "oracle_all_rays_seeds", "oracle_fire_ray", "oracle_camera_fire_ray",
+                     "oracle_world_ray_intersection", "oracle_renderer_solve", "oracle_pcg_new", "oracle_pcg_random",
+                     "oracle_pcg_random_float", "oracle_pigment_get_color", "oracle_scatter_ray",
+                     "oracle_create_onb_from_z", "oracle_transform", "oracle_math_eval"):
+            getattr(h, name).restype = C.c_int
+        _lib = h
+    return _lib
+
+
+def fptr(a):
+    return a.ctypes.data_as(P(C.c_float))
+
+
+class OraclePcg:
+    """Pcg mirror whose draws come from the oracle (state / inc are Python ints)."""
+
+    def __init__(self, init_state=42, init_seq=54):
+        p = _abi.rt_pcg()
+        lib().oracle_pcg_new(init_state, init_seq, C.byref(p))
+        self.state, self.inc = p.state, p.inc
+
+    def random_float(self):
+        return float(self.random_floats(1)[0])
+
+    def random_floats(self, n):
+        p = _abi.rt_pcg(self.state, self.inc)
+        out = np.empty(n, dtype=np.float32)
+        lib().oracle_pcg_random_float(C.byref(p), n, fptr(out))
+        self.state, self.inc = p.state, p.inc
+        return out
+
+
+def fire_all_rays(flat, cam, rr, width, height, init_state=42, init_seq=54, aa=1, rows=None,
+                  math_mode=MATH_STRICT, n_threads=8):
+    """oracle ImageTracer::fire_all_rays -> (image (rows, w, 3) float32, stats dict)."""
+    r0, r1 = (0, height) if rows is None else rows
+    out = np.zeros((max(r1 - r0, 0), width, 3), dtype=np.float32)
+    st = _abi.rt_stats()
+    rc = lib().oracle_fire_all_rays(*flat.args(), C.byref(cam), C.byref(rr), width, height, init_state, init_seq,
+                                    aa, r0, r1, math_mode, n_threads, fptr(out), C.byref(st))
+    assert rc == 0
+    return out, st.as_dict()
+
+
+def world_ray_intersection(flat, rays, math_mode=MATH_STRICT):
+    n = len(rays)
+    arr = (_abi.rt_ray * max(1, n))(*rays)
+    hits = (_abi.rt_hit * max(1, n))()
+    rc = lib().oracle_world_ray_intersection(*flat.args(), arr, n, math_mode, hits)
+    assert rc == 0
+    return list(hits)[:n]
+
+
+def renderer_solve(flat, rr, rays, pcgs, math_mode=MATH_STRICT):
+    """rays: list of rt_ray; pcgs: list of (state, inc) -> (colors (n,3), new pcgs)."""
+    n = len(rays)
+    arr = (_abi.rt_ray * max(1, n))(*rays)
+    pa = (_abi.rt_pcg * max(1, n))(*[_abi.rt_pcg(s, i) for s, i in pcgs])
+    out = np.zeros((max(1, n), 3), dtype=np.float32)
+    rc = lib().oracle_renderer_solve(*flat.args(), C.byref(rr), arr, pa, n, math_mode, fptr(out))
+    assert rc == 0
+    return out[:n], [(pa[i].state, pa[i].inc) for i in range(n)]
+
+
+def math_eval(fn, a, b=None, math_mode=MATH_STRICT):
+    a = np.ascontiguousarray(a, dtype=np.float32)
+    b = a if b is None else np.ascontiguousarray(b, dtype=np.float32)
+    out = np.empty_like(a)
+    lib().oracle_math_eval(fn, math_mode, fptr(a), fptr(b), a.size, fptr(out))
+    return out
