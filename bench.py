@@ -1,0 +1,213 @@
+#!/usr/bin/env python3
+"""bench.py — headline benchmark: path samples/s of examples/demo.yml, pathtracer, 1920x1080.
+
+A step = one ImageTracer::fire_all_rays pass (one frame) with the scene already resident in HBM
+and the image left in HBM.  N GPUs split the SAME frame by row tiles dealt round-robin (strong
+scaling), one process per GPU, one RCCL gather of the parts into rank 0's image per step.
+
+  python bench.py --gpus 1 --steps K --warmup W
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+         --master-port P bench.py --gpus N --steps K --warmup W
+"""
+import argparse
+import ctypes as C
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+WIDTH, HEIGHT, AA = 1920, 1080, 1
+NUM_OF_RAYS, MAX_DEPTH, RR_LIMIT = 10, 3, 3
+INIT_STATE, INIT_SEQ = 42, 54
+PEAK_FP32_VECTOR_TFLOPS = 157.3     # MI355X_MICROARCH.md: spec, FMA counted as 2 flop
+PEAK_STRICT_NOFMA_TFLOPS = 78.6     # same issue rate with unfused mul/add (reference forbids FMA)
+
+
+def partition_rows(height, part, n_parts, tile_rows):
+    """Rows of `part` (host mirror of part_rows() in csrc/rt_host.inc)."""
+    rows = []
+    n_tiles = (height + tile_rows - 1) // tile_rows
+    for j in range(part, n_tiles, n_parts):
+        rows.extend(range(j * tile_rows, min((j + 1) * tile_rows, height)))
+    return rows
+
+
+def flops_per_ray(n_spheres, n_planes):
+    """60 per sphere test, 40 per plane test, +62 hit tail, +46 shade."""
+    return 60 * n_spheres + 40 * n_planes + 62 + 46
+
+
+def cpu_baseline(flat, cam, rr, threads):
+    """The CPU checker (oracle/, the reference's algorithm restated) on this box's host cores."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import oracle_lib as O
+    t0 = time.perf_counter()
+    _, st = O.fire_all_rays(flat, cam, rr, WIDTH, HEIGHT, INIT_STATE, INIT_SEQ, AA, math_mode=O.MATH_LIBM,
+                            n_threads=threads)
+    dt = time.perf_counter() - t0
+    return {"value": WIDTH * HEIGHT * AA * AA / dt, "unit": "path samples/s", "cores": threads, "kind": "port",
+            "sample": f"the full {WIDTH}x{HEIGHT} frame once ({st['rays']} rays, {dt:.2f} s wall incl. serial all_rays)",
+            "rays_per_s": st["rays"] / dt}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--tile-rows", type=int, default=1)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+    import rustracer_amd as ra
+    from rustracer_amd import _abi
+    from rustracer_amd.scenes import demo_camera, demo_world
+    from rustracer_amd.world import flatten_camera
+
+    world_size = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world_size != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world_size}: launch with torch.distributed.run")
+    torch.cuda.set_device(local_rank)
+    lib = _abi.lib()
+    _abi.check(lib.rt_init(local_rank))
+    if world_size > 1:
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    scene = demo_world()
+    flat = scene.flatten()
+    cam = flatten_camera(demo_camera(WIDTH, HEIGHT))
+    rr = ra.PathTracer(scene, ra.BLACK, NUM_OF_RAYS, MAX_DEPTH, RR_LIMIT).flatten()
+    dev = scene.device()          # World resident in HBM before the timed region
+    stream = torch.cuda.current_stream()
+
+    part = _abi.rt_partition(rank, world_size, args.tile_rows)
+    sizes = [lib.rt_partition_pixels(WIDTH, HEIGHT, C.byref(_abi.rt_partition(p, world_size, args.tile_rows)))
+             for p in range(world_size)]
+    stride = max(sizes)
+    NB = 3                         # rotating part buffers so gather(i) overlaps render(i+1)
+    bufs = [torch.zeros((stride, 3), dtype=torch.float32, device="cuda") for _ in range(NB)]
+    image = torch.zeros((HEIGHT, WIDTH, 3), dtype=torch.float32, device="cuda")
+    gathered = None
+    if world_size > 1 and rank == 0:
+        gathered = [torch.zeros((world_size, stride, 3), dtype=torch.float32, device="cuda") for _ in range(NB)]
+    side = torch.cuda.Stream() if world_size > 1 else None
+    pending = [None] * NB
+
+    def render(buf, stats=None):
+        _abi.check(lib.rt_render(dev.handle, C.byref(cam), C.byref(rr), WIDTH, HEIGHT, INIT_STATE, INIT_SEQ, AA,
+                                 C.byref(part), buf.data_ptr(), stream.cuda_stream, stats))
+
+    def step(i, ev=None):
+        slot = i % NB
+        if pending[slot] is not None:
+            pending[slot].wait()           # stream-level: the part buffer is free again
+            pending[slot] = None
+        if ev:
+            ev[0].record(stream)
+        render(bufs[slot] if world_size > 1 else image.view(-1, 3))
+        if ev:
+            ev[1].record(stream)
+        if world_size > 1:
+            if rank == 0:
+                glist = list(gathered[slot].unbind(0))
+                work = dist.gather(bufs[slot], gather_list=glist, dst=0, async_op=True)
+                with torch.cuda.stream(side):
+                    work.wait()
+                    _abi.check(lib.rt_unpack_parts(gathered[slot].data_ptr(), stride, world_size, args.tile_rows,
+                                                   WIDTH, HEIGHT, image.data_ptr(), side.cuda_stream))
+                    done = torch.cuda.Event()
+                    done.record(side)
+                pending[slot] = _EventWork(done, stream)
+            else:
+                pending[slot] = dist.gather(bufs[slot], dst=0, async_op=True)
+
+    class _EventWork:
+        def __init__(self, event, st):
+            self.event, self.st = event, st
+
+        def wait(self):
+            self.st.wait_event(self.event)
+
+    def sync_all():
+        for s in range(NB):
+            if pending[s] is not None:
+                pending[s].wait()
+                pending[s] = None
+        torch.cuda.synchronize()
+        if world_size > 1:
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    # one instrumented launch: ray counters of this rank's part (deterministic, same every step)
+    st = _abi.rt_stats()
+    render(bufs[0] if world_size > 1 else image.view(-1, 3), C.byref(st))
+    my_rays = st.rays
+
+    for i in range(args.warmup):
+        step(i)
+    sync_all()
+    events = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        step(i, events[i])
+    sync_all()
+    dt = time.perf_counter() - t0
+
+    kernel_ms = sum(a.elapsed_time(b) for a, b in events) / max(1, args.steps)
+    t = torch.tensor([dt, kernel_ms, float(my_rays)], dtype=torch.float64, device="cuda")
+    if world_size > 1:
+        tmax = t.clone()
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        tsum = t.clone()
+        dist.all_reduce(tsum, op=dist.ReduceOp.SUM)
+        dt, kernel_ms_max, total_rays = float(tmax[0]), float(tmax[1]), float(tsum[2])
+    else:
+        kernel_ms_max, total_rays = kernel_ms, float(my_rays)
+
+    if rank == 0:
+        samples_per_step = WIDTH * HEIGHT * AA * AA
+        value = samples_per_step * args.steps / dt
+        fpr = flops_per_ray(dev_n_spheres(flat), dev_n_planes(flat))
+        # roofline of the dominant kernel (k_render) on THIS rank: algorithmic flops / device time
+        achieved = my_rays * fpr / (kernel_ms * 1e-3) / 1e12
+        out = {
+            "metric": "path samples/sec (node) demo.yml pathtracer 1080p",
+            "value": value, "unit": "path samples/s", "n_gpus": world_size, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True,
+            "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"examples/demo.yml scene (4 shapes), pathtracer n={NUM_OF_RAYS} d={MAX_DEPTH} "
+                                   f"rr={RR_LIMIT}, {WIDTH}x{HEIGHT}, aa={AA}, seeds {INIT_STATE}/{INIT_SEQ}",
+                       "parallelism": f"row tiles ({args.tile_rows} rows) round-robin over {world_size} GPU(s), "
+                                      "RCCL gather to rank 0" if world_size > 1 else "1 GPU, whole frame",
+                       "rays_per_frame": total_rays, "rays_per_s": total_rays * args.steps / dt},
+            "roofline": {"bound": "valu", "achieved": achieved, "peak": PEAK_FP32_VECTOR_TFLOPS, "unit": "TFLOP/s",
+                         "frac": achieved / PEAK_FP32_VECTOR_TFLOPS, "traffic": None,
+                         "kernel": "k_render", "kernel_ms": kernel_ms, "rays_per_launch": my_rays,
+                         "flops_per_ray": fpr, "peak_strict_nofma": PEAK_STRICT_NOFMA_TFLOPS,
+                         "frac_strict_nofma": achieved / PEAK_STRICT_NOFMA_TFLOPS},
+        }
+        if world_size == 1 and not args.no_cpu_baseline:
+            threads = int(os.environ.get("OMP_NUM_THREADS", "0")) or min(os.cpu_count() or 1, 16)
+            out["cpu_baseline"] = cpu_baseline(flat, cam, rr, threads)
+        print(json.dumps(out), flush=True)
+    if world_size > 1:
+        dist.destroy_process_group()
+
+
+def dev_n_spheres(flat):
+    return sum(1 for i in range(flat.n_shapes) if flat.shapes[i].kind == 0)
+
+
+def dev_n_planes(flat):
+    return sum(1 for i in range(flat.n_shapes) if flat.shapes[i].kind == 1)
+
+
+if __name__ == "__main__":
+    main()

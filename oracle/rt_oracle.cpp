@@ -513,6 +513,9 @@ struct ImageTracer {
 
 struct Rays { uint64_t seq; size_t first_ray; };
 
+// optional diagnostics sink: World::ray_intersection calls per pixel of the next fire_all_rays
+uint32_t* g_pixel_rays = nullptr;
+
 }  // namespace
 
 // =============================================================================================
@@ -577,6 +580,7 @@ int oracle_fire_all_rays(const rt_shape* shapes, uint32_t n_shapes, const rt_mat
             const size_t e = b + grain < n_pixels ? b + grain : n_pixels;
             for (size_t i = b; i < e; ++i) {
                 Color color = {0.f, 0.f, 0.f};
+                const uint64_t rays_before = cnt.rays;
                 Pcg ppcg(init_state, all_rays[i].seq);
                 for (size_t k = 0; k < rays_per_pixel; ++k) {
                     cnt.samples++;
@@ -586,6 +590,7 @@ int oracle_fire_all_rays(const rt_shape* shapes, uint32_t n_shapes, const rt_mat
                 out_rgb[3 * i + 0] = color.r;
                 out_rgb[3 * i + 1] = color.g;
                 out_rgb[3 * i + 2] = color.b;
+                if (g_pixel_rays) g_pixel_rays[i] = (uint32_t)(cnt.rays - rays_before);
             }
         }
         counters[tid] = cnt;
@@ -608,6 +613,12 @@ int oracle_fire_all_rays(const rt_shape* shapes, uint32_t n_shapes, const rt_mat
         stats->kernel_ms = std::chrono::duration<double, std::milli>(t2 - t1).count();  // par_iter part
         stats->total_ms = std::chrono::duration<double, std::milli>(t2 - t0).count();   // incl. all_rays
     }
+    return 0;
+}
+
+// Diagnostics: per-pixel ray counts of subsequent oracle_fire_all_rays calls (NULL = off).
+int oracle_set_pixel_ray_counter(uint32_t* buf) {
+    g_pixel_rays = buf;
     return 0;
 }
 

@@ -111,6 +111,14 @@ def lib():
             raise RuntimeError(
                 f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; "
                 "g.build()'` (hipcc, gfx950). There is no CPU fallback.")
+        # PyTorch-ROCm bundles its own libamdhip64.so.7 / libhsa-runtime64; two HSA runtimes in one
+        # process cannot both open the GPU.  Import torch first so that librustracer_amd.so binds
+        # to the runtime already in the process (torch is the plumbing for device memory, streams
+        # and torch.distributed; a C/C++ host without torch simply gets /opt/rocm's runtime).
+        try:
+            import torch  # noqa: F401
+        except ImportError:
+            pass
         handle = C.CDLL(LIB_PATH)
         for name, (res, args) in SIGNATURES.items():
             fn = getattr(handle, name)  # AttributeError if the symbol is not exported

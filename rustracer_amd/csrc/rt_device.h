@@ -229,17 +229,18 @@ __device__ __forceinline__ int closest_hit(const DShape* __restrict__ shapes, ui
 // Pigment::get_color (src/material.rs:32-36, :54-70, :86-96, :106-115)
 // ---------------------------------------------------------------------------------------------
 __device__ __forceinline__ Vec3 pigment_color(const DPigment* __restrict__ p, const float* __restrict__ texels, float u, float v) {
-    Vec3 c;
+    // all fields are fetched up front (one batch of loads, no dependent round trips)
     const uint32_t kind = p->kind;
-    if (kind == RT_PIGMENT_UNIFORM) {
-        c.x = p->c1[0]; c.y = p->c1[1]; c.z = p->c1[2];
-    } else if (kind == RT_PIGMENT_CHECKERED) {
-        const float steps = (float)p->steps;
+    const float c1x = p->c1[0], c1y = p->c1[1], c1z = p->c1[2];
+    const float c2x = p->c2[0], c2y = p->c2[1], c2z = p->c2[2];
+    const uint32_t isteps = p->steps;
+    Vec3 c = {c1x, c1y, c1z};                         // UniformPigment (material.rs:32-36)
+    if (kind == RT_PIGMENT_CHECKERED) {               // material.rs:86-96
+        const float steps = (float)isteps;
         const uint32_t int_u = rt_f32_to_u32_sat(__builtin_floorf(u * steps));
         const uint32_t int_v = rt_f32_to_u32_sat(__builtin_floorf(v * steps));
-        if ((int_u % 2u) == (int_v % 2u)) { c.x = p->c1[0]; c.y = p->c1[1]; c.z = p->c1[2]; }
-        else { c.x = p->c2[0]; c.y = p->c2[1]; c.z = p->c2[2]; }
-    } else {
+        if ((int_u % 2u) != (int_v % 2u)) { c.x = c2x; c.y = c2y; c.z = c2z; }
+    } else if (kind == RT_PIGMENT_IMAGE) {            // material.rs:54-70
         const uint32_t w = p->tex_w, h = p->tex_h;
         uint32_t col = rt_f32_to_u32_sat(u * (float)w);
         uint32_t row = rt_f32_to_u32_sat(v * (float)h);

@@ -31,10 +31,8 @@ namespace rtd {
 
 // Everything a render / solve launch needs, passed by value (kernarg -> SGPRs).
 struct RenderParams {
-    const DShape* shapes;
-    const DMaterial* materials;
-    const float* texels;
     uint32_t n_shapes;
+    uint32_t scene_in_lds;           // 1: shapes + per-shape materials are staged in LDS
     // camera (src/camera.rs)
     uint32_t cam_kind;
     float cam_distance, cam_aspect;
@@ -78,16 +76,54 @@ struct LevelStack {
 };
 
 // MODE 0: image render (pixel queue).  MODE 1: batch Renderer::solve on caller-supplied (ray, pcg).
-template <bool AFFINE, bool STACK_LDS, int MODE>
-__global__ __launch_bounds__(RT_BLOCK) void k_render(const RenderParams P) {
-    extern __shared__ float lds_stack[];
+// NS > 0: the scene has exactly NS shapes (affine): the closest-hit scan is fully unrolled with the
+// inverse matrices held in SGPRs for the whole launch, and the scene is staged in LDS.
+// The scene tables are separate __restrict__ const arguments so that wave-uniform reads of them
+// are scalar (SMEM) loads.
+template <bool AFFINE, bool STACK_LDS, int MODE, int NS>
+__global__ __launch_bounds__(RT_BLOCK) void k_render(const RenderParams P, const DShape* __restrict__ g_shapes,
+                                                     const DMaterial* __restrict__ g_materials,
+                                                     const float* __restrict__ texels) {
+    extern __shared__ float4 lds_raw[];
     const uint32_t tid = threadIdx.x;
     const uint32_t lane = tid & 63u;
     const uint32_t gtid = blockIdx.x * RT_BLOCK + tid;
 
+    // ---- LDS: [DShape x n][DMaterial x n (one per shape)][recursion stack] ----
+    const bool scene_lds = (NS > 0) ? true : (P.scene_in_lds != 0u);
+    const uint32_t n_staged = scene_lds ? P.n_shapes : 0u;
+    DShape* lds_shapes = reinterpret_cast<DShape*>(lds_raw);
+    DMaterial* lds_mats = reinterpret_cast<DMaterial*>(lds_shapes + n_staged);
+    float* lds_stack = reinterpret_cast<float*>(lds_mats + n_staged);
+    if (scene_lds) {
+        uint32_t* dst_s = reinterpret_cast<uint32_t*>(lds_shapes);
+        const uint32_t* src_s = reinterpret_cast<const uint32_t*>(g_shapes);
+        for (uint32_t i = tid; i < n_staged * (uint32_t)(sizeof(DShape) / 4); i += RT_BLOCK) dst_s[i] = src_s[i];
+        uint32_t* dst_m = reinterpret_cast<uint32_t*>(lds_mats);
+        constexpr uint32_t MW = sizeof(DMaterial) / 4;
+        for (uint32_t i = tid; i < n_staged * MW; i += RT_BLOCK) {
+            const uint32_t sh = i / MW, j = i - sh * MW;
+            dst_m[i] = reinterpret_cast<const uint32_t*>(g_materials + g_shapes[sh].material)[j];
+        }
+        __syncthreads();
+    }
+
     LevelStack<STACK_LDS> stack;
     if (STACK_LDS) { stack.base = lds_stack + tid; stack.stride = RT_BLOCK; }
     else { stack.base = P.gstack + gtid; stack.stride = P.total_threads; }
+
+    // NS > 0: inverse matrices (rows 0..2) and kinds of all NS shapes, wave-uniform for the launch
+    float sinv[NS > 0 ? NS : 1][12];
+    uint32_t skind[NS > 0 ? NS : 1];
+    if (NS > 0) {
+#pragma unroll
+        for (int i = 0; i < NS; ++i) {
+#pragma unroll
+            for (int j = 0; j < 12; ++j)
+                sinv[i][j] = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(g_shapes[i].inv[j])));
+            skind[i] = __builtin_amdgcn_readfirstlane(g_shapes[i].kind);
+        }
+    }
 
     const uint32_t aa2 = P.aa * P.aa;
     const uint32_t n_rays_per_hit = P.num_of_rays;
@@ -243,19 +279,37 @@ __global__ __launch_bounds__(RT_BLOCK) void k_render(const RenderParams P) {
                 // render.rs:137-139 (only reachable for a caller-supplied deep ray)
             } else {
                 float t;
-                const int best = closest_hit<AFFINE>(P.shapes, P.n_shapes, ro, rd, rtmin, rtmax, t);
+                int best;
+                if (NS > 0) {
+                    best = -1;
+                    t = 0.0f;
+#pragma unroll
+                    for (int i = 0; i < NS; ++i) {
+                        const Vec3 o = xform_point<true>(sinv[i], ro.x, ro.y, ro.z);
+                        const Vec3 d = xform_vector(sinv[i], rd.x, rd.y, rd.z);
+                        float ti = 0.0f;
+                        bool hit;
+                        if (skind[i] == RT_SHAPE_SPHERE) hit = sphere_t(o, d, rtmin, rtmax, ti);
+                        else hit = plane_t(o, d, rtmin, rtmax, ti);
+                        if (hit && (best < 0 || ti < t)) { best = i; t = ti; }
+                    }
+                } else {
+                    best = closest_hit<AFFINE>(g_shapes, P.n_shapes, ro, rd, rtmin, rtmax, t);
+                }
                 n_rays += 1;
                 if (best < 0) {
                     vr = P.bg[0]; vg = P.bg[1]; vb = P.bg[2];
                 } else if (P.algorithm == RT_ALGO_ONOFF) {
                     vr = P.fg[0]; vg = P.fg[1]; vb = P.fg[2];   // render.rs:61-66
                 } else {
-                    const DShape* S = P.shapes + best;
+                    const DShape* S;
+                    const DMaterial* M;
+                    if (scene_lds) { S = lds_shapes + best; M = lds_mats + best; }
+                    else { S = g_shapes + best; M = g_materials + S->material; }
                     const bool want_uv = S->needs_uv != 0u;
                     const HitRec h = hit_record<AFFINE>(S, ro, rd, t, want_uv);
-                    const DMaterial* M = P.materials + S->material;
-                    Vec3 hc = pigment_color(&M->brdf_pigment, P.texels, h.u, h.v);
-                    const Vec3 em = pigment_color(&M->emitted, P.texels, h.u, h.v);
+                    Vec3 hc = pigment_color(&M->brdf_pigment, texels, h.u, h.v);
+                    const Vec3 em = pigment_color(&M->emitted, texels, h.u, h.v);
                     if (P.algorithm == RT_ALGO_FLAT) {
                         vr = em.x + hc.x; vg = em.y + hc.y; vb = em.z + hc.z;   // render.rs:83-84
                     } else {

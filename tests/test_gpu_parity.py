@@ -1,0 +1,313 @@
+"""GPU parity: the HIP render core (through the C-ABI) against the CPU oracle.
+
+Bar: bit-exact.  The oracle runs with math_mode = STRICT (include/rt_strict_math.h, the same
+definition the kernels use), so every f32 of every pixel, hit record and PCG state must be equal,
+and the ray counters must match exactly.  Every test here needs a real MI355X.
+"""
+import ctypes as C
+import math
+
+import numpy as np
+import pytest
+
+import oracle_lib as O
+import rustracer_amd as ra
+from rustracer_amd import _abi
+from rustracer_amd.scenes import demo_camera, demo_world
+from rustracer_amd.world import flatten_camera, flatten_world, to_rt_ray
+
+pytestmark = pytest.mark.gpu
+
+
+def bits(a):
+    return np.ascontiguousarray(a, dtype=np.float32).view(np.uint32)
+
+
+def assert_bit_equal(a, b, what=""):
+    a, b = np.asarray(a, dtype=np.float32), np.asarray(b, dtype=np.float32)
+    assert a.shape == b.shape
+    neq = bits(a) != bits(b)
+    # NaN payloads may differ between x86 and gfx950; NaN == NaN counts as equal
+    neq &= ~(np.isnan(a) & np.isnan(b))
+    assert not neq.any(), f"{what}: {int(neq.sum())} of {neq.size} floats differ, first at {np.argwhere(neq)[0]}"
+
+
+def gpu_image(world, cam, renderer, w, h, init_state=42, init_seq=54, aa=1):
+    img = ra.HdrImage(w, h)
+    tracer = ra.ImageTracer(img, cam)
+    tracer.fire_all_rays(renderer, init_state, init_seq, aa)
+    return img.pixels, tracer.last_stats
+
+
+def oracle_image(world, cam, renderer, w, h, init_state=42, init_seq=54, aa=1):
+    return O.fire_all_rays(flatten_world(world), flatten_camera(cam), renderer.flatten(), w, h, init_state,
+                           init_seq, aa, math_mode=O.MATH_STRICT)
+
+
+def check_image(world, cam, renderer, w, h, **kw):
+    g, gs = gpu_image(world, cam, renderer, w, h, **kw)
+    o, os_ = oracle_image(world, cam, renderer, w, h, **kw)
+    assert_bit_equal(g, o, "image")
+    for k in ("rays", "samples", "sphere_tests", "plane_tests", "diffuse_scatters", "specular_scatters"):
+        assert gs[k] == os_[k], (k, gs[k], os_[k])
+    return g, gs
+
+
+# ---- PCG (src/random.rs:56-81) ---------------------------------------------------------------
+def test_pcg_known_answers_and_random_seeds():
+    rng = np.random.default_rng(1)
+    s = np.concatenate([[42, 38, 0, 2**64 - 1], rng.integers(0, 2**63, 1000, dtype=np.uint64)]).astype(np.uint64)
+    q = np.concatenate([[54, 62, 0, 2**64 - 1], rng.integers(0, 2**63, 1000, dtype=np.uint64)]).astype(np.uint64)
+    n, k = len(s), 37
+    got = np.zeros(n * k, dtype=np.uint32)
+    ref = np.zeros(n * k, dtype=np.uint32)
+    u64, u32 = C.POINTER(C.c_uint64), C.POINTER(C.c_uint32)
+    _abi.check(_abi.lib().rt_pcg_random(s.ctypes.data_as(u64), q.ctypes.data_as(u64), n, k, got.ctypes.data_as(u32)))
+    O.lib().oracle_pcg_random(s.ctypes.data_as(u64), q.ctypes.data_as(u64), n, k, ref.ctypes.data_as(u32))
+    assert got[:6].tolist() == [2707161783, 2068313097, 3122475824, 2211639955, 3215226955, 3421331566]
+    assert np.array_equal(got, ref)
+
+
+# ---- shared strict math: host == device, bit for bit -------------------------------------------
+def _gpu_math(fn, a, b=None):
+    a = np.ascontiguousarray(a, dtype=np.float32)
+    b = a if b is None else np.ascontiguousarray(b, dtype=np.float32)
+    out = np.empty_like(a)
+    _abi.check(_abi.lib().rt_strict_math_eval(fn, O.fptr(a), O.fptr(b), a.size, O.fptr(out)))
+    return out
+
+
+def test_strict_math_host_device_bit_equal():
+    rng = np.random.default_rng(7)
+    n = 1 << 20
+    rf = (rng.integers(0, 2**32, n, dtype=np.uint64).astype(np.float32) * np.float32(2.0**-32)).astype(np.float32)
+    phi = (np.float32(6.2831855) * rf).astype(np.float32)       # the hot path's argument range
+    wide = rng.uniform(-1000, 1000, n).astype(np.float32)
+    for fn, a in ((0, phi), (1, phi), (0, wide), (1, wide)):
+        assert_bit_equal(_gpu_math(fn, a), O.math_eval(fn, a), f"sin/cos fn={fn}")
+    y = rng.normal(size=n).astype(np.float32)
+    x = rng.normal(size=n).astype(np.float32)
+    y[:8] = [0.0, -0.0, 0.0, -0.0, 1.0, -1.0, np.inf, np.nan]
+    x[:8] = [1.0, 1.0, -1.0, -1.0, 0.0, -0.0, np.inf, 1.0]
+    assert_bit_equal(_gpu_math(2, y, x), O.math_eval(2, y, x), "atan2")
+    z = rng.uniform(-1.0000001, 1.0000001, n).astype(np.float32)
+    z[:4] = [1.0, -1.0, 0.0, 1.0000001]
+    assert_bit_equal(_gpu_math(3, z), O.math_eval(3, z), "acos")
+    # IEEE f32 divide and sqrt incl. subnormals
+    a = rng.integers(0, 2**32, n, dtype=np.uint64).astype(np.uint32).view(np.float32)
+    b = rng.integers(0, 2**32, n, dtype=np.uint64).astype(np.uint32).view(np.float32)
+    with np.errstate(all="ignore"):
+        assert_bit_equal(_gpu_math(4, a, b), O.math_eval(4, a, b), "div")
+        assert_bit_equal(_gpu_math(5, np.abs(a)), O.math_eval(5, np.abs(a)), "sqrt")
+
+
+# ---- World::ray_intersection (src/shape.rs:223-568, src/world.rs:62-92) ------------------------
+def _rays(rng, n):
+    rays = []
+    for _ in range(n):
+        o = rng.uniform(-4, 4, 3)
+        d = rng.normal(size=3)
+        rays.append(to_rt_ray(ra.Ray(origin=tuple(o), dir=tuple(d))))
+    return rays
+
+
+def _hits_equal(g, o):
+    assert g.hit == o.hit
+    if g.hit:
+        assert g.shape == o.shape
+        assert_bit_equal(list(g.world_point) + list(g.normal) + list(g.uv) + [g.t],
+                         list(o.world_point) + list(o.normal) + list(o.uv) + [o.t], "hit record")
+
+
+def test_reference_shape_known_answers_on_gpu():
+    w = ra.World()
+    w.add(ra.Sphere())
+    h = w.ray_intersection(ra.Ray(origin=(0, 0, 2), dir=(0, 0, -1)))
+    assert h and abs(h.t - 1) < 1e-4 and list(h.world_point) == [0, 0, 1] and list(h.normal) == [0, 0, 1]
+    assert w.ray_intersection(ra.Ray(origin=(0, 10, 2), dir=(0, 0, -1))) is None
+    h = w.ray_intersection(ra.Ray(origin=(0, 0, 0), dir=(1, 0, 0)))   # from inside
+    assert h and list(h.normal) == [-1, 0, 0] and abs(h.uv[1] - 0.5) < 1e-4
+    p = ra.World()
+    p.add(ra.Plane())
+    h = p.ray_intersection(ra.Ray(origin=(-4.25, -7.75, 1), dir=(0, 0, -1)))
+    assert h and abs(h.uv[0] - 0.75) < 1e-4 and abs(h.uv[1] - 0.25) < 1e-4
+    assert p.ray_intersection(ra.Ray(origin=(0, 0, 1), dir=(1, 0, 0))) is None
+
+
+def test_world_ray_intersection_random_rays():
+    rng = np.random.default_rng(3)
+    world = demo_world()
+    world.add(ra.Sphere(ra.translation((0.5, -1, 0.3)) * ra.scaling((0.5, 1.5, 0.25)) * ra.rotation_y(0.3)))
+    world.add(ra.Plane(ra.rotation_x(1.1) * ra.translation((0, 0, -2))))
+    world.add(ra.Sphere())
+    world.add(ra.Sphere())  # exact duplicate: tie must go to the earlier index
+    rays = _rays(rng, 4000)
+    rays.append(to_rt_ray(ra.Ray(origin=(0, 0, 5), dir=(0, 0, 0))))          # zero direction
+    rays.append(to_rt_ray(ra.Ray(origin=(math.nan, 0, 5), dir=(0, 0, -1))))  # NaN origin (plane "hits" with t=NaN)
+    rays.append(to_rt_ray(ra.Ray(origin=(0, 0, 5), dir=(0, 0, -1), tmin=1.0, tmax=4.95)))
+    g = world.ray_intersections(rays)
+    o = O.world_ray_intersection(flatten_world(world), rays, O.MATH_STRICT)
+    for a, b in zip(g, o):
+        _hits_equal(a, b)
+    assert sum(h.hit for h in g) > 1000
+
+
+def test_non_affine_matrix_takes_divide_branch():
+    m = np.eye(4, dtype=np.float32)
+    m[3, 3] = 2.0
+    m[3, 0] = 0.25
+    inv = np.linalg.inv(m.astype(np.float64)).astype(np.float32)
+    world = ra.World()
+    world.add(ra.Sphere(ra.Transformation(m, inv)))
+    world.add(ra.Plane(ra.translation((0, 0, -1))))
+    rays = _rays(np.random.default_rng(5), 1000)
+    g = world.ray_intersections(rays)
+    o = O.world_ray_intersection(flatten_world(world), rays, O.MATH_STRICT)
+    for a, b in zip(g, o):
+        _hits_equal(a, b)
+
+
+def test_empty_world_and_empty_batch():
+    w = ra.World()
+    assert w.ray_intersection(ra.Ray()) is None
+    assert w.ray_intersections([]) == []
+
+
+# ---- Renderer::solve (src/render.rs:221-313) ---------------------------------------------------
+def test_furnace_on_gpu_matches_oracle_and_closed_form():
+    pcg = O.OraclePcg()
+    gpcg = ra.Pcg()
+    for _ in range(10):
+        emitted = pcg.random_float()
+        reflectance = float(np.float32(pcg.random_float()) * np.float32(0.9))
+        gpcg.state, gpcg.inc = pcg.state, pcg.inc
+        mat = ra.Material(ra.DiffuseBRDF(ra.UniformPigment((reflectance,) * 3)), ra.UniformPigment((emitted,) * 3))
+        w = ra.World()
+        w.add(ra.Sphere(ra.Transformation(), mat))
+        pt = ra.PathTracer(w, ra.BLACK, 1, 100, 101)     # max_depth 100: global-memory recursion stack
+        got = pt.solve(ra.Ray(), gpcg)
+        ref, new = O.renderer_solve(flatten_world(w), pt.flatten(), [to_rt_ray(ra.Ray())], [(pcg.state, pcg.inc)])
+        pcg.state, pcg.inc = new[0]
+        assert_bit_equal(got, ref[0], "furnace radiance")
+        assert (gpcg.state, gpcg.inc) == (pcg.state, pcg.inc)
+        assert abs(got[0] - emitted / (1.0 - reflectance)) < 1e-4
+
+
+def test_flat_onoff_background_known_answers_on_gpu():
+    red, green, blue = (1, 0, 0), (0, 1, 0), (0, 0, 1)
+    mat = ra.Material(ra.DiffuseBRDF(ra.CheckeredPigment(red, blue, 2)), ra.UniformPigment(green))
+    w = ra.World()
+    w.add(ra.Sphere(ra.Transformation(), mat))
+    flat = ra.FlatRenderer(w, ra.BLACK)
+    pcg = ra.Pcg()
+    assert flat.solve(ra.Ray(origin=(-2, 3, 0)), pcg) == (0, 0, 0)
+    assert flat.solve(ra.Ray(origin=(-2, 0.5, 0.5)), pcg) == (1, 1, 0)
+    assert flat.solve(ra.Ray(origin=(-2, -0.5, 0.5)), pcg) == (0, 1, 1)
+    onoff = ra.OnOffRenderer(w, ra.BLACK, ra.WHITE)
+    assert onoff.solve(ra.Ray(origin=(-2, 3, 0)), pcg) == (0, 0, 0)
+    assert onoff.solve(ra.Ray(origin=(-2, 0, 0)), pcg) == (1, 1, 1)
+    w2 = ra.World()
+    w2.add(ra.Sphere(ra.translation((2, 0, 0))))
+    assert ra.PathTracer(w2, ra.BLACK, 1000, 1000, 0).solve(ra.Ray(), pcg) == (0, 0, 0)
+    assert ra.DummyRenderer().solve(ra.Ray(), pcg) == (1, 2, 3)
+
+
+def test_solve_batch_random_rays_pathtracer():
+    rng = np.random.default_rng(11)
+    world = demo_world()
+    flat = flatten_world(world)
+    rays = _rays(rng, 512)
+    pcgs = [(int(rng.integers(0, 2**63)), int(rng.integers(0, 2**62)) * 2 + 1) for _ in rays]
+    for n, d, rr in [(10, 3, 3), (3, 5, 2), (1, 2, 0), (0, 3, 3), (4, 0, 0), (4, 1, 5)]:
+        r = ra.PathTracer(world, (0.1, 0.2, 0.3), n, d, rr).flatten()
+        arr = (_abi.rt_ray * len(rays))(*rays)
+        pa = (_abi.rt_pcg * len(rays))(*[_abi.rt_pcg(s, i) for s, i in pcgs])
+        out = np.zeros((len(rays), 3), dtype=np.float32)
+        _abi.check(_abi.lib().rt_renderer_solve(world.device().handle, C.byref(r), arr, pa, len(rays), O.fptr(out)))
+        ref, new = O.renderer_solve(flat, r, rays, pcgs)
+        assert_bit_equal(out, ref, f"solve n={n} d={d} rr={rr}")
+        assert [(pa[i].state, pa[i].inc) for i in range(len(rays))] == new
+
+
+# ---- ImageTracer::fire_all_rays: BASELINE configs at oracle-sized resolutions ------------------
+def test_c1_onoff_mask_pixel_exact_640x480():
+    world = demo_world()
+    g, st = check_image(world, demo_camera(640, 480), ra.OnOffRenderer(world, ra.BLACK, ra.WHITE), 640, 480)
+    assert st["samples"] == 640 * 480 and set(np.unique(g).tolist()) <= {0.0, 1.0}
+
+
+def test_c2_flat_aa4_demo():
+    world = demo_world()
+    check_image(world, demo_camera(320, 240), ra.FlatRenderer(world, ra.BLACK), 320, 240, aa=4)
+
+
+def test_c3_pathtracer_demo_small():
+    world = demo_world()
+    g, st = check_image(world, demo_camera(192, 108), ra.PathTracer(world, ra.BLACK, 10, 3, 3), 192, 108)
+    assert st["rays"] > 192 * 108 * 10
+
+
+def test_pathtracer_aa2_other_seeds_orthogonal():
+    world = demo_world()
+    check_image(world, demo_camera(96, 64, angle_deg=35.0, orthogonal=True),
+                ra.PathTracer(world, (0.05, 0.0, 0.1), 3, 4, 2), 96, 64, init_state=7, init_seq=2**40 + 3, aa=2)
+
+
+def test_image_pigment_and_checkered_sphere():
+    rng = np.random.default_rng(2)
+    tex = ra.HdrImage(17, 9)
+    tex.pixels = rng.uniform(0, 1, (9, 17, 3)).astype(np.float32)
+    world = ra.World()
+    world.add(ra.Sphere(ra.scaling((50, 50, 50)), ra.Material(ra.DiffuseBRDF(ra.UniformPigment(ra.BLACK)), ra.ImagePigment(tex))))
+    world.add(ra.Plane(ra.translation((0, 0, -1)), ra.Material(ra.DiffuseBRDF(ra.ImagePigment(tex)), ra.UniformPigment(ra.BLACK))))
+    world.add(ra.Sphere(ra.Transformation(), ra.Material(ra.DiffuseBRDF(ra.CheckeredPigment((0.9, 0.1, 0.1), (0.1, 0.9, 0.1), 6)), ra.UniformPigment(ra.BLACK))))
+    world.add(ra.Sphere(ra.translation((0, 1.5, 0)), ra.Material(ra.SpecularBRDF(ra.CheckeredPigment((0.8, 0.8, 0.8), (0.3, 0.3, 0.9), 4)), ra.UniformPigment(ra.BLACK))))
+    cam = ra.PerspectiveCamera(1.0, 1.5, ra.translation((-3, 0.5, 0.3)))
+    check_image(world, cam, ra.FlatRenderer(world, ra.BLACK), 150, 100, aa=2)
+    check_image(world, cam, ra.PathTracer(world, ra.BLACK, 4, 3, 2), 150, 100)
+
+
+def test_dummy_renderer_coverage_and_degenerate_sizes():
+    cam = ra.PerspectiveCamera(1.0, 2.0, ra.Transformation())
+    g, st = gpu_image(ra.World(), cam, ra.DummyRenderer(), 4, 2, 0, 0, 1)   # imagetracer.rs:148-163
+    assert np.all(g == np.array([1, 2, 3], dtype=np.float32)) and st["rays"] == 0
+    g, _ = gpu_image(ra.World(), cam, ra.DummyRenderer(), 0, 0)
+    assert g.size == 0
+    world = demo_world()
+    check_image(world, demo_camera(1, 1), ra.PathTracer(world, ra.BLACK, 2, 2, 1), 1, 1)
+    check_image(world, demo_camera(67, 3), ra.PathTracer(world, ra.BLACK, 2, 2, 1), 67, 3, aa=3)
+
+
+def test_row_tile_partition_and_unpack_reassemble_the_image():
+    import torch
+    world = demo_world()
+    w, h = 160, 90
+    cam, rr = flatten_camera(demo_camera(w, h)), ra.PathTracer(world, ra.BLACK, 3, 2, 1).flatten()
+    whole, _ = gpu_image(world, demo_camera(w, h), ra.PathTracer(world, ra.BLACK, 3, 2, 1), w, h)
+    lib = _abi.lib()
+    for n_parts, tile_rows in [(2, 1), (3, 4), (8, 2), (4, 100)]:
+        sizes = [lib.rt_partition_pixels(w, h, C.byref(_abi.rt_partition(p, n_parts, tile_rows))) for p in range(n_parts)]
+        assert sum(sizes) == w * h
+        stride = max(sizes)
+        parts = torch.zeros((n_parts, stride, 3), dtype=torch.float32, device="cuda")
+        for p in range(n_parts):
+            part = _abi.rt_partition(p, n_parts, tile_rows)
+            _abi.check(lib.rt_render(world.device().handle, C.byref(cam), C.byref(rr), w, h, 42, 54, 1, C.byref(part),
+                                     parts[p].data_ptr(), torch.cuda.current_stream().cuda_stream, None))
+        image = torch.empty((h, w, 3), dtype=torch.float32, device="cuda")
+        _abi.check(lib.rt_unpack_parts(parts.data_ptr(), stride, n_parts, tile_rows, w, h, image.data_ptr(),
+                                       torch.cuda.current_stream().cuda_stream))
+        torch.cuda.synchronize()
+        assert_bit_equal(image.cpu().numpy(), whole, f"partition {n_parts}x{tile_rows}")
+
+
+def test_errors_are_reported_not_swallowed():
+    lib = _abi.lib()
+    world = demo_world()
+    cam, rr = flatten_camera(demo_camera(8, 8)), ra.PathTracer(world, ra.BLACK, 1, 1, 1).flatten()
+    assert lib.rt_render(world.device().handle, C.byref(cam), C.byref(rr), 8, 8, 42, 54, 0, None, None, None, None) != 0
+    assert b"antialiasing" in lib.rt_last_error()
+    bad = flatten_world(world)
+    bad.shapes[0].material = 99
+    assert not lib.rt_scene_create(*bad.args())
+    assert b"material index" in lib.rt_last_error()
