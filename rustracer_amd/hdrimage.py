@@ -52,11 +52,11 @@ class HdrImage:
         def line():
             raw = stream.readline()
             if not raw.endswith(b"\n"):
-                raise HdrImageErr("invalid pfm file format: missing eol")
+                raise HdrImageErr("invalid pfm file format: expected eol as separator inside header")
             try:
                 return raw.decode("ascii").rstrip()
             except UnicodeDecodeError:
-                raise HdrImageErr("invalid pfm file format: non-ascii header")
+                raise HdrImageErr("impossible to read from pfm file: stream did not contain valid UTF-8")
         if line() != "PF":
             raise HdrImageErr("invalid pfm file format: wrong magic inside header")
         width, height = _parse_img_shape(line())
@@ -130,26 +130,29 @@ class HdrImage:
 
 
 def _parse_img_shape(line):
-    """src/hdrimage.rs parse_img_shape: exactly two unsigned integers separated by one space."""
-    parts = line.split(" ")
+    """src/hdrimage.rs:357-370: two u32 separated by one or more spaces."""
+    parts = [p for p in line.split(" ") if p != ""]
     if len(parts) != 2:
-        raise HdrImageErr("invalid pfm file format: invalid image shape")
-    try:
-        w, h = int(parts[0]), int(parts[1])
-    except ValueError:
-        raise HdrImageErr("invalid pfm file format: invalid image shape")
-    if w < 0 or h < 0:
-        raise HdrImageErr("invalid pfm file format: invalid image shape")
-    return w, h
+        raise HdrImageErr("invalid pfm file format: wrong image shape inside header")
+    dims = []
+    for text, what in zip(parts, ("image width", "image height")):
+        if not text.isdigit():  # u32::from_str rejects signs other than '+', decimals, letters
+            if not (text.startswith("+") and text[1:].isdigit()):
+                raise HdrImageErr(f"impossible to parse {what} from pfm header")
+        v = int(text)
+        if v > 0xFFFFFFFF:
+            raise HdrImageErr(f"impossible to parse {what} from pfm header")
+        dims.append(v)
+    return dims[0], dims[1]
 
 
 def _parse_endianness(line):
     try:
         v = float(line)
     except ValueError:
-        raise HdrImageErr("invalid pfm file format: invalid endianness")
+        raise HdrImageErr("impossible to parse endianness from pfm header")
     if v > 0:
         return "big"
     if v < 0:
         return "little"
-    raise HdrImageErr("invalid pfm file format: invalid endianness")
+    raise HdrImageErr("invalid pfm file format: invalid endianness inside header")

@@ -1,0 +1,24 @@
+"""Condense gpurun_out/prof (rocprofv3 csv) into a text summary for profiles/."""
+import csv, glob, collections, sys
+root = sys.argv[1] if len(sys.argv) > 1 else "gpurun_out/prof"
+print("== rocprofv3 --kernel-trace --stats (bench.py --steps 20 --warmup 3) ==")
+for f in glob.glob(root + "/trace/*/*_kernel_stats.csv"):
+    for r in csv.DictReader(open(f)):
+        print(f"{r['Name'][:110]:110s} calls={r['Calls']:>4s} avg_ns={float(r['AverageNs']):12.0f} pct={r['Percentage']}")
+print("\n== PMC (mean per dispatch) ==")
+for d in ("pmc1", "pmc2", "pmc3", "pmc4"):
+    for f in glob.glob(f"{root}/{d}/*/*_counter_collection.csv"):
+        agg = collections.defaultdict(lambda: collections.defaultdict(list))
+        for r in csv.DictReader(open(f)):
+            k = "k_render" if "k_render" in r["Kernel_Name"] else "k_classify" if "k_classify" in r["Kernel_Name"] else None
+            if k:
+                agg[k][r["Counter_Name"]].append(float(r["Counter_Value"]))
+                meta = {x: r[x] for x in ("Grid_Size", "Workgroup_Size", "LDS_Block_Size", "VGPR_Count", "SGPR_Count", "Scratch_Size")}
+                agg[k]["_meta"] = meta
+        for k, cs in agg.items():
+            for name, v in cs.items():
+                if name == "_meta":
+                    continue
+                print(f"{k:11s} {name:26s} {sum(v)/len(v):.5g}")
+            if d == "pmc1":
+                print(f"{k:11s} launch {cs['_meta']}")
