@@ -18,6 +18,8 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <type_traits>
+
 #include "rt_device.h"
 
 #pragma clang fp contract(off)
@@ -66,6 +68,8 @@ struct RenderParams {
     const uint32_t* order;           // [RT_NCLASS][n_local] local pixel indices of each class
     const uint64_t* pix_mstate;      // [n_local] master PCG state at each pixel's first jitter draw
     uint32_t idle_min;               // refill when at least this many teams of a wave are idle
+    uint64_t surv_mult[16], surv_geom[16];   // PCG advance by 2*num_of_rays*s draws, s = 0..15
+    uint32_t surv_spec;              // 1: enumerate survivor counts at the last traced level
     // diagnostics (RUSTRACER_DEBUG_WAVES): per wave {t_start, t_end (100 MHz), rounds, active-lane rounds, refills}
     unsigned long long* debug_waves;
     unsigned long long* counters;    // [0] rays [1] samples [2] diffuse [3] specular
@@ -208,30 +212,30 @@ __constant__ JumpTable c_jump = make_jump_table();
 //         recursion of PathTracer::solve (src/render.rs:136-172); only the latency changes.
 // The scene tables are separate __restrict__ const arguments so that wave-uniform reads of them
 // are scalar (SMEM) loads.
-template <bool AFFINE, bool STACK_LDS, int MODE, int NS, int T>
+template <bool AFFINE, bool STACK_LDS, int MODE, int NS, int T, int T2>
 __global__ __launch_bounds__(RT_BLOCK) void k_render(const RenderParams P, const DShape* __restrict__ g_shapes,
                                                      const DMaterial* __restrict__ g_materials,
                                                      const float* __restrict__ texels) {
     static_assert(T == 1 || T == 2 || T == 4 || T == 8 || T == 16, "team size");
+    static_assert(T2 == 0 || ((T2 == 2 || T2 == 4 || T2 == 8 || T2 == 16) && T == 1 && MODE == 0 && STACK_LDS), "tail team size");
     extern __shared__ float4 lds_raw[];
     const uint32_t tid = threadIdx.x;
     const uint32_t lane = tid & 63u;
     const uint32_t gtid = blockIdx.x * RT_BLOCK + tid;
-    const uint32_t jj = (T > 1) ? (lane & (uint32_t)(T - 1)) : 0u;   // sibling slot of this lane
-    const uint32_t team0 = lane & ~(uint32_t)(T - 1);                // first lane of the team
-    const bool leader = (jj == 0u);
+    constexpr bool ANY_TEAMS = (T > 1) || (T2 > 1);
 
     // ---- LDS: [jump table (T>1)][DShape x n][DMaterial x n (one per shape)][recursion stack] ----
     uint64_t* lds_jump = reinterpret_cast<uint64_t*>(lds_raw);
-    constexpr uint32_t JUMP_BYTES = (T > 1) ? (uint32_t)sizeof(JumpTable) : 0u;
+    constexpr uint32_t JUMP_BYTES = ANY_TEAMS ? (uint32_t)sizeof(JumpTable) + 256u : 0u;   // + survivor tables
     const bool scene_lds = (NS > 0) ? true : (P.scene_in_lds != 0u);
     const uint32_t n_staged = scene_lds ? P.n_shapes : 0u;
     DShape* lds_shapes = reinterpret_cast<DShape*>(reinterpret_cast<unsigned char*>(lds_raw) + JUMP_BYTES);
     DMaterial* lds_mats = reinterpret_cast<DMaterial*>(lds_shapes + n_staged);
     float* lds_stack = reinterpret_cast<float*>(lds_mats + n_staged);
-    if (T > 1) {
+    if (ANY_TEAMS) {
         const uint64_t* src = reinterpret_cast<const uint64_t*>(&c_jump);
         for (uint32_t i = tid; i < 128u; i += RT_BLOCK) lds_jump[i] = src[i];
+        if (tid < 16u) { lds_jump[128u + tid] = P.surv_mult[tid]; lds_jump[144u + tid] = P.surv_geom[tid]; }
     }
     if (scene_lds) {
         uint32_t* dst_s = reinterpret_cast<uint32_t*>(lds_shapes);
@@ -244,7 +248,7 @@ __global__ __launch_bounds__(RT_BLOCK) void k_render(const RenderParams P, const
             dst_m[i] = reinterpret_cast<const uint32_t*>(g_materials + g_shapes[sh].material)[j];
         }
     }
-    if (T > 1 || scene_lds) __syncthreads();
+    if (ANY_TEAMS || scene_lds) __syncthreads();
 
     LevelStack<STACK_LDS> stack;
     if (STACK_LDS) { stack.base = lds_stack + tid; stack.stride = RT_BLOCK; }
@@ -301,6 +305,13 @@ __global__ __launch_bounds__(RT_BLOCK) void k_render(const RenderParams P, const
         cls_end1 = cls_end0 + P.class_counts[1];
     }
 
+    // The round loop, instantiated per team size TT.  stop_live > 0: return true (instead of running
+    // to completion) once the queue is exhausted and at most stop_live pixels are left in the wave.
+    auto run_rounds = [&](auto team_tag, const uint32_t stop_live) -> bool {
+    constexpr int TT = decltype(team_tag)::value;
+    const uint32_t jj = (TT > 1) ? (lane & (uint32_t)(TT - 1)) : 0u;   // candidate slot of this lane
+    const uint32_t team0 = lane & ~(uint32_t)(TT - 1);                 // first lane of the team
+    const bool leader = (jj == 0u);
     for (;;) {
         // =====================================================================================
         // generate / compact: teams without a solve in flight take the next sample or pixel
@@ -336,7 +347,7 @@ __global__ __launch_bounds__(RT_BLOCK) void k_render(const RenderParams P, const
             while (wantmask != 0ull) {
                 if (wcur == wend) {
                     // heavy classes are handed out in small chunks (longest-processing-time first)
-                    constexpr uint32_t TEAMS = 64u / (uint32_t)T;     // pixels a wave holds at once
+                    constexpr uint32_t TEAMS = 64u / (uint32_t)TT;     // pixels a wave holds at once
                     uint32_t chunk = TEAMS;
                     if (P.sorted) {
                         chunk = (wend < cls_end0) ? 4u : (wend < cls_end1) ? 16u : RT_CHUNK;
@@ -367,7 +378,7 @@ __global__ __launch_bounds__(RT_BLOCK) void k_render(const RenderParams P, const
                 wcur += cnt;
                 wantmask = __ballot(lead_want);
             }
-            if (T > 1) {
+            if (TT > 1) {
                 q = __shfl(q, team0);
                 newpix = __shfl((int)newpix, team0) != 0;
             }
@@ -409,17 +420,29 @@ __global__ __launch_bounds__(RT_BLOCK) void k_render(const RenderParams P, const
                 busy = true;
             }
         }
-        if (__ballot(busy) == 0ull) break;  // queue empty and every team retired
+        if (__ballot(busy) == 0ull) return false;  // queue empty and every team retired
+        if (stop_live != 0u && exhausted) {
+            const uint32_t live = (uint32_t)__popcll(__ballot(busy || (q != RT_INVALID && samp < aa2)));
+            if (live <= stop_live) return true;
+        }
         // =====================================================================================
         // this round's candidate rays: the level-0 ray, or up to T siblings of the open hit
         // =====================================================================================
         const uint32_t depth = base_depth + lvl;     // Ray.depth of the rays traced this round
-        uint32_t n_cand = 0;
-        if (busy) {
-            if (lvl == 0u) n_cand = 1u;
-            else { n_cand = n_children - kcount; if (n_cand > (uint32_t)T) n_cand = (uint32_t)T; }
+        // Candidate (cj, cs) of this lane: sibling kcount+cj, assuming cs of the earlier siblings of this
+        // round consumed the long draw count.  Below the last traced level cs = 0 and cj = jj.  At the
+        // last level (depth == max_depth: a hit cannot open, it consumes pred or pred + 2n draws) the
+        // team enumerates all (cj, cs <= cj) in triangular order, so several siblings resolve per round
+        // whatever their roulette outcomes were.
+        const bool last_level = (TT > 1) && (lvl > 0u) && (depth == P.max_depth) && (P.surv_spec != 0u);
+        uint32_t cj = jj, cs = 0u;
+        if (last_level) {
+            cj = (jj >= 15u) ? 5u : (jj >= 10u) ? 4u : (jj >= 6u) ? 3u : (jj >= 3u) ? 2u : (jj >= 1u) ? 1u : 0u;
+            cs = jj - ((cj * (cj + 1u)) >> 1);
         }
-        const bool act = jj < n_cand;
+        uint32_t n_rem = 0;          // rays this level still has to start
+        if (busy) n_rem = (lvl == 0u) ? 1u : (n_children - kcount);
+        const bool act = busy && ((lvl == 0u) ? (jj == 0u) : (cj < n_rem));
         if (P.debug_waves) {
             dbg_rounds += 1u; dbg_lanes += (uint32_t)__popcll(__ballot(act));
             if (busy) dbg_pix_rounds += 1u;
@@ -444,9 +467,10 @@ __global__ __launch_bounds__(RT_BLOCK) void k_render(const RenderParams P, const
                 o = ro; d = rd; tmin = rtmin; tmax = rtmax;
             } else {
                 // BRDF::scatter_ray of sibling kcount+jj (render.rs:160-166)
-                if (T > 1) {
-                    const uint32_t m = jj * (2u + pred);
+                if (TT > 1) {
+                    const uint32_t m = cj * (2u + pred);
                     st = st * lds_jump[m] + pinc * lds_jump[64u + m];
+                    if (last_level) st = st * lds_jump[128u + cs] + pinc * lds_jump[144u + cs];
                 }
                 const float rf0 = pcg_random_float(st, pinc);
                 const float rf1 = pcg_random_float(st, pinc);
@@ -553,32 +577,68 @@ __global__ __launch_bounds__(RT_BLOCK) void k_render(const RenderParams P, const
             uint32_t n_valid = 1u, last = 0u;
             bool last_leaf = leaf;
             uint32_t traced_valid = traced ? 1u : 0u;
-            if (T > 1) {
-                const bool bad = act && !(leaf && (lvl == 0u || consumed == pred));
-                const uint32_t tmask = (T >= 32) ? 0xFFFFFFFFu : ((1u << T) - 1u);
-                const uint32_t tb = (uint32_t)(__ballot(bad) >> team0) & tmask;
-                const uint32_t first_bad = tb ? (uint32_t)__builtin_ctz(tb) : n_cand;
-                n_valid = first_bad + 1u < n_cand ? first_bad + 1u : n_cand;
-                last = n_valid - 1u;
-                last_leaf = __shfl((int)leaf, team0 + last) != 0;
-                const uint32_t trb = (uint32_t)(__ballot(traced) >> team0) & tmask;
-                traced_valid = (uint32_t)__popc(trb & ((1u << n_valid) - 1u));
-            }
-            const uint32_t n_acc = n_valid - (last_leaf ? 0u : 1u);
             // fold the kept leaves into the level, in sibling order (render.rs:168 / imagetracer.rs:119)
             float pr, pg, pb;
             if (lvl == 0u) { pr = vr; pg = vg; pb = vb; }
             else { pr = hc_r * vr; pg = hc_g * vg; pb = hc_b * vb; }
             float tr = (lvl == 0u) ? acc_r : cu_r, tg = (lvl == 0u) ? acc_g : cu_g, tb_ = (lvl == 0u) ? acc_b : cu_b;
-            if (T > 1) {
+            if (TT > 1) {
+                constexpr uint32_t tmask = (1u << TT) - 1u;
+                const uint32_t b_leaf = (uint32_t)(__ballot(act && leaf) >> team0) & tmask;
+                const uint32_t b_traced = (uint32_t)(__ballot(traced) >> team0) & tmask;
+                if (!last_level) {
+                    // linear layout: keep siblings up to and including the first that is not a
+                    // leaf with the predicted draw count
+                    const bool bad = act && !(leaf && (lvl == 0u || consumed == pred));
+                    const uint32_t tb = (uint32_t)(__ballot(bad) >> team0) & tmask;
+                    uint32_t n_cand = n_rem < (uint32_t)TT ? n_rem : (uint32_t)TT;
+                    const uint32_t first_bad = tb ? (uint32_t)__builtin_ctz(tb) : n_cand;
+                    n_valid = first_bad + 1u < n_cand ? first_bad + 1u : n_cand;
+                    last = n_valid - 1u;
+                    last_leaf = ((b_leaf >> last) & 1u) != 0u;
+                    traced_valid = (uint32_t)__popc(b_traced & ((1u << n_valid) - 1u));
+                    const uint32_t n_acc = n_valid - (last_leaf ? 0u : 1u);
 #pragma unroll
-                for (int i = 0; i < T; ++i) {
-                    const float qr = __shfl(pr, team0 + i), qg = __shfl(pg, team0 + i), qb = __shfl(pb, team0 + i);
-                    if ((uint32_t)i < n_acc) { tr = tr + qr; tg = tg + qg; tb_ = tb_ + qb; }
+                    for (int i = 0; i < TT; ++i) {
+                        const float qr = __shfl(pr, team0 + i), qg = __shfl(pg, team0 + i), qb = __shfl(pb, team0 + i);
+                        if ((uint32_t)i < n_acc) { tr = tr + qr; tg = tg + qg; tb_ = tb_ + qb; }
+                    }
+                } else {
+                    // triangular layout: walk the siblings in order, following the survivor count
+                    constexpr int JM = (TT >= 16) ? 6 : (TT >= 8) ? 4 : (TT >= 4) ? 3 : 2;
+                    const uint32_t b_act = (uint32_t)(__ballot(act) >> team0) & tmask;
+                    const uint32_t b_lo = (uint32_t)(__ballot(act && leaf && consumed == pred) >> team0) & tmask;
+                    const uint32_t b_hi = (uint32_t)(__ballot(act && leaf && consumed == pred + 2u * n_children) >> team0) & tmask;
+                    uint32_t ch[JM];
+                    uint32_t surv = 0u;
+                    bool cont = true;
+                    n_valid = 0u;
+                    traced_valid = 0u;
+#pragma unroll
+                    for (int j = 0; j < JM; ++j) {
+                        const uint32_t idx = (uint32_t)((j * (j + 1)) >> 1) + surv;
+                        const bool ok = cont && idx < (uint32_t)TT && ((b_act >> idx) & 1u) != 0u;
+                        ch[j] = idx < (uint32_t)TT ? idx : 0u;
+                        if (ok) {
+                            n_valid = (uint32_t)j + 1u;
+                            last = idx;
+                            traced_valid += (b_traced >> idx) & 1u;
+                        }
+                        const bool hi = ((b_hi >> idx) & 1u) != 0u;
+                        cont = ok && ((((b_lo >> idx) & 1u) != 0u) || hi);
+                        if (ok && hi) surv += 1u;
+                    }
+                    last_leaf = ((b_leaf >> last) & 1u) != 0u;
+                    const uint32_t n_acc = n_valid - (last_leaf ? 0u : 1u);
+#pragma unroll
+                    for (int j = 0; j < JM; ++j) {
+                        const float qr = __shfl(pr, team0 + ch[j]), qg = __shfl(pg, team0 + ch[j]), qb = __shfl(pb, team0 + ch[j]);
+                        if ((uint32_t)j < n_acc) { tr = tr + qr; tg = tg + qg; tb_ = tb_ + qb; }
+                    }
                 }
                 pstate = __shfl(st, team0 + last);
             } else {
-                if (n_acc) { tr = tr + pr; tg = tg + pg; tb_ = tb_ + pb; }
+                if (last_leaf) { tr = tr + pr; tg = tg + pg; tb_ = tb_ + pb; }
                 pstate = st;
             }
             if (lvl == 0u) { acc_r = tr; acc_g = tg; acc_b = tb_; }
@@ -603,7 +663,7 @@ __global__ __launch_bounds__(RT_BLOCK) void k_render(const RenderParams P, const
                     stack.st(s, 15, cin.x); stack.st(s, 16, cin.y); stack.st(s, 17, cin.z);
                     stack.st(s, 18, __uint_as_float((kcount << 1) | cur_brdf));
                 }
-                if (T > 1) {
+                if (TT > 1) {
                     const uint32_t src = team0 + last;
                     hc_r = __shfl(ihc.x, src); hc_g = __shfl(ihc.y, src); hc_b = __shfl(ihc.z, src);
                     em_r = __shfl(iem.x, src); em_g = __shfl(iem.y, src); em_b = __shfl(iem.z, src);
@@ -648,6 +708,61 @@ __global__ __launch_bounds__(RT_BLOCK) void k_render(const RenderParams P, const
                 }
             }
         }
+    }
+
+    };   // run_rounds
+
+    if (T2 == 0) {
+        (void)run_rounds(std::integral_constant<int, T>{}, 0u);
+    } else if (run_rounds(std::integral_constant<int, 1>{}, 64u / (uint32_t)(T2 > 0 ? T2 : 1))) {
+        // ---- tail: the queue is empty and at most 64/T2 pixels of this wave are unfinished.  Pack
+        // them into teams of T2 lanes (each lane of a team gets a copy of the pixel's state and of its
+        // LDS stack) and finish them with sibling / survivor speculation: the frame ends when the
+        // longest per-pixel chain of dependent rays ends, and idle lanes are free. ----
+        constexpr uint32_t TT2 = (uint32_t)(T2 > 0 ? T2 : 1);
+        // retire finished pixels still waiting for a refill event
+        if (!busy && q != RT_INVALID && samp == aa2) {
+            float* o = P.out + 3ull * q;
+            o[0] = acc_r * P.inv_samples; o[1] = acc_g * P.inv_samples; o[2] = acc_b * P.inv_samples;
+            q = RT_INVALID;
+            if (dbg_pix_rounds > dbg_max_pix_rounds) dbg_max_pix_rounds = dbg_pix_rounds;
+            dbg_pix_rounds = 0;
+        }
+        const bool live = busy || (q != RT_INVALID);
+        unsigned long long lm = __ballot(live);
+        const uint32_t n_live = (uint32_t)__popcll(lm);
+        const uint32_t tt = lane / TT2;
+        for (uint32_t i = 0; i < tt; ++i) lm &= lm - 1ull;       // drop the tt lowest live lanes
+        const bool has = tt < n_live;
+        const uint32_t src = has ? (uint32_t)__builtin_ctzll(lm) : lane;
+        // counters stay with their lane; everything else moves
+        q = __shfl(q, src); samp = __shfl(samp, src);
+        mstate = __shfl(mstate, src); pstate = __shfl(pstate, src); pinc = __shfl(pinc, src);
+        acc_r = __shfl(acc_r, src); acc_g = __shfl(acc_g, src); acc_b = __shfl(acc_b, src);
+        grow = __shfl(grow, src); gcol = __shfl(gcol, src);
+        busy = __shfl((int)busy, src) != 0;
+        ro.x = __shfl(ro.x, src); ro.y = __shfl(ro.y, src); ro.z = __shfl(ro.z, src);
+        rd.x = __shfl(rd.x, src); rd.y = __shfl(rd.y, src); rd.z = __shfl(rd.z, src);
+        rtmin = __shfl(rtmin, src); rtmax = __shfl(rtmax, src);
+        lvl = __shfl(lvl, src); base_depth = __shfl(base_depth, src);
+        hc_r = __shfl(hc_r, src); hc_g = __shfl(hc_g, src); hc_b = __shfl(hc_b, src);
+        em_r = __shfl(em_r, src); em_g = __shfl(em_g, src); em_b = __shfl(em_b, src);
+        cu_r = __shfl(cu_r, src); cu_g = __shfl(cu_g, src); cu_b = __shfl(cu_b, src);
+        kcount = __shfl(kcount, src); cur_brdf = __shfl(cur_brdf, src);
+        cw.x = __shfl(cw.x, src); cw.y = __shfl(cw.y, src); cw.z = __shfl(cw.z, src);
+        cn.x = __shfl(cn.x, src); cn.y = __shfl(cn.y, src); cn.z = __shfl(cn.z, src);
+        cin.x = __shfl(cin.x, src); cin.y = __shfl(cin.y, src); cin.z = __shfl(cin.z, src);
+        dbg_pix_rounds = __shfl(dbg_pix_rounds, src);
+        if (!has) { q = RT_INVALID; busy = false; }
+        // LDS stack: every (slot, field) is read by all lanes before any lane overwrites it
+        // (LDS operations of one wave execute in order)
+        const float* sbase = lds_stack + (tid - lane + src);
+        for (uint32_t i = 0; i < P.stack_slots * RT_NF; ++i) {
+            const float v = sbase[i * RT_BLOCK];
+            stack.base[i * RT_BLOCK] = v;
+        }
+        exhausted = true;
+        (void)run_rounds(std::integral_constant<int, (T2 > 0 ? T2 : 1)>{}, 0u);
     }
 
     if (P.debug_waves && lane == 0) {
