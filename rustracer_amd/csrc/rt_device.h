@@ -32,6 +32,23 @@ struct __attribute__((aligned(16))) DShape {
 };
 static_assert(sizeof(DShape) == 160, "DShape layout");
 
+// Scan table entry (64 B): what the closest-hit loop needs per shape, read wave-uniformly
+// (LDS broadcast when the table is staged, scalar loads otherwise).
+struct __attribute__((aligned(16))) DScan {
+    float inv[12];      // Transformation.invm rows 0..2, row-major
+    uint32_t kind;      // RT_SHAPE_*
+    uint32_t material;  // index into the material table (the shape index when staged in LDS)
+    uint32_t needs_uv;  // 1 if either pigment of the material reads (u,v)
+    uint32_t pad;
+};
+static_assert(sizeof(DScan) == 64, "DScan layout");
+// Transformation.m rows 0..2 (48 B), read per lane once per ray for the winner.
+struct __attribute__((aligned(16))) DMRows { float m[12]; };
+static_assert(sizeof(DMRows) == 48, "DMRows layout");
+// Last rows of invm and m (32 B); only read when some matrix of the scene is not affine.
+struct __attribute__((aligned(16))) DWRows { float inv_w[4]; float m_w[4]; };
+static_assert(sizeof(DWRows) == 32, "DWRows layout");
+
 struct DPigment {
     uint32_t kind;      // RT_PIGMENT_*
     float c1[3];
@@ -223,6 +240,120 @@ __device__ __forceinline__ int closest_hit(const DShape* __restrict__ shapes, ui
         }
     }
     return best;
+}
+
+// ---------------------------------------------------------------------------------------------
+// The same, on the split layout (DScan / DMRows / DWRows) used by the render passes
+// ---------------------------------------------------------------------------------------------
+struct Rows3 { float4 r0, r1, r2; };
+__device__ __forceinline__ Rows3 load_rows(const float* __restrict__ p) {
+    const float4* q = reinterpret_cast<const float4*>(p);
+    Rows3 r; r.r0 = q[0]; r.r1 = q[1]; r.r2 = q[2];
+    return r;
+}
+// T*Point (src/transformation.rs:163-195): rows 0..2 in R; W = last row (read only if !AFFINE).
+template <bool AFFINE>
+__device__ __forceinline__ Vec3 rows_point(const Rows3& R, const float* __restrict__ W, float x, float y, float z) {
+    Vec3 r;
+    r.x = R.r0.x * x + R.r0.y * y + R.r0.z * z + R.r0.w;
+    r.y = R.r1.x * x + R.r1.y * y + R.r1.z * z + R.r1.w;
+    r.z = R.r2.x * x + R.r2.y * y + R.r2.z * z + R.r2.w;
+    if (!AFFINE) {
+        const float w = x * W[0] + y * W[1] + z * W[2] + W[3];
+        if (!(w == 1.0f)) {
+            r.x = r.x / w;
+            r.y = r.y / w;
+            r.z = r.z / w;
+        }
+    }
+    return r;
+}
+// T*Vector (src/transformation.rs:133-143)
+__device__ __forceinline__ Vec3 rows_vector(const Rows3& R, float x, float y, float z) {
+    Vec3 r;
+    r.x = R.r0.x * x + R.r0.y * y + R.r0.z * z;
+    r.y = R.r1.x * x + R.r1.y * y + R.r1.z * z;
+    r.z = R.r2.x * x + R.r2.y * y + R.r2.z * z;
+    return r;
+}
+// T*Normal with I = invm rows (src/transformation.rs:145-161)
+__device__ __forceinline__ Vec3 rows_normal(const Rows3& I, float x, float y, float z) {
+    Vec3 r;
+    r.x = I.r0.x * x + I.r1.x * y + I.r2.x * z;
+    r.y = I.r0.y * x + I.r1.y * y + I.r2.y * z;
+    r.z = I.r0.z * x + I.r1.z * y + I.r2.z * z;
+    return r;
+}
+
+// World::ray_intersection (src/world.rs:32-50) over a DScan table that every lane reads at the
+// same index (LDS broadcast or scalar loads): linear scan, strict `<`, earliest shape wins ties.
+template <bool AFFINE>
+__device__ __forceinline__ int scan_closest_hit(const DScan* __restrict__ scan, const DWRows* __restrict__ wrows,
+                                                uint32_t n_shapes, Vec3 ro, Vec3 rd, float tmin, float tmax,
+                                                float& best_t) {
+    int best = -1;
+    best_t = 0.0f;
+    for (uint32_t i = 0; i < n_shapes; ++i) {
+        const DScan* __restrict__ S = scan + i;
+        const Rows3 R = load_rows(S->inv);
+        const uint32_t kind = (uint32_t)__builtin_amdgcn_readfirstlane((int)S->kind);
+        const Vec3 o = rows_point<AFFINE>(R, AFFINE ? nullptr : wrows[i].inv_w, ro.x, ro.y, ro.z);
+        const Vec3 d = rows_vector(R, rd.x, rd.y, rd.z);
+        float t = 0.0f;
+        bool hit;
+        if (kind == RT_SHAPE_SPHERE) hit = sphere_t(o, d, tmin, tmax, t);
+        else hit = plane_t(o, d, tmin, tmax, t);
+        if (hit && (best < 0 || t < best_t)) {
+            best = (int)i;
+            best_t = t;
+        }
+    }
+    return best;
+}
+
+// HitRecord fields of the winner (src/shape.rs:134-142, :205-213) on the split layout.  want_geom
+// false skips world_point and normal (a node that cannot scatter never reads them).
+template <bool AFFINE>
+__device__ __forceinline__ HitRec scan_hit_record(const DScan* __restrict__ S, const DMRows* __restrict__ MR,
+                                                  const DWRows* __restrict__ WR, Vec3 ro, Vec3 rd, float t,
+                                                  bool want_uv, bool want_geom) {
+    HitRec h;
+    const Rows3 I = load_rows(S->inv);
+    const Vec3 o = rows_point<AFFINE>(I, AFFINE ? nullptr : WR->inv_w, ro.x, ro.y, ro.z);
+    const Vec3 d = rows_vector(I, rd.x, rd.y, rd.z);
+    const float hx = o.x + d.x * t, hy = o.y + d.y * t, hz = o.z + d.z * t;   // inv_ray.at(t)
+    h.world_point = {0.f, 0.f, 0.f};
+    h.normal = {0.f, 0.f, 1.f};
+    h.u = 0.0f;
+    h.v = 0.0f;
+    const bool sphere = (S->kind == RT_SHAPE_SPHERE);
+    if (want_geom) {
+        const Rows3 M = load_rows(MR->m);
+        h.world_point = rows_point<AFFINE>(M, AFFINE ? nullptr : WR->m_w, hx, hy, hz);
+        float nx, ny, nz, dp;
+        if (sphere) {
+            dp = hx * d.x + hy * d.y + hz * d.z;
+            nx = hx; ny = hy; nz = hz;
+        } else {
+            dp = 0.0f * d.x + 0.0f * d.y + 1.0f * d.z;
+            nx = 0.0f; ny = 0.0f; nz = 1.0f;
+        }
+        if (!(dp < 0.0f)) { nx = -nx; ny = -ny; nz = -nz; }
+        h.normal = rows_normal(I, nx, ny, nz);
+    }
+    if (want_uv) {
+        if (sphere) {
+            float u = rt_atan2f(hy, hx) / 6.2831854820251465f;  // 2.0 * PI in f32
+            const float v = rt_acosf(hz) / 3.1415927410125732f; // PI in f32
+            if (u < 0.0f) u += 1.0f;
+            h.u = u;
+            h.v = v;
+        } else {
+            h.u = hx - __builtin_floorf(hx);
+            h.v = hy - __builtin_floorf(hy);
+        }
+    }
+    return h;
 }
 
 // ---------------------------------------------------------------------------------------------

@@ -1,20 +1,25 @@
 // rt_kernels.hip — gfx950 kernels of the render core.
 //
-// k_render is a persistent, register-resident path-state machine (one lane = one pixel in
-// flight, exactly one ray in flight per lane):
+// Wavefront path tracing over PATH-STATE queues.  The reference threads ONE Pcg through the whole
+// recursion of PathTracer::solve (src/render.rs:136-172), so the draw order inside a pixel is
+// depth-first and data dependent: a queue entry is therefore a pixel (its whole recursion state,
+// exactly one ray in flight), never a single ray.  A frame is a short sequence of passes of one
+// kernel, k_pass:
 //
-//   generate : lanes without a ray take the next sample of their pixel, or a new pixel from the
-//              wave's private chunk of the pixel queue (one global atomic per 64-pixel chunk);
-//              the master PCG of ImageTracer::all_rays is reproduced by LCG jump-ahead.
-//   intersect: World::ray_intersection — wave-uniform scan of the shape table (scalar loads).
+//   generate : pass 0 takes fresh pixels (master PCG of ImageTracer::all_rays reproduced by LCG
+//              jump-ahead, src/imagetracer.rs:61-84); later passes take parked path states from
+//              the SoA queue in HBM the previous pass wrote.
+//   intersect: World::ray_intersection — wave-uniform scan of the shape table staged in LDS.
 //   shade    : HitRecord of the winner, pigments, renderer logic, Russian roulette; advances the
 //              pixel's depth-first recursion by one node, consuming PCG draws in reference order.
-//   compact  : finished lanes are refilled in place (wave64 ballot + prefix rank), so a wave
-//              stays full until the pixel queue is empty.
+//   compact  : a lane whose pixel finished refills in place (wave64 ballot + prefix rank over the
+//              wave's chunk of the queue); a pixel that used up the pass's round budget is PARKED:
+//              its state is appended to the next pass's queue (ballot + prefix rank, one atomic per
+//              wave).  The next pass therefore starts with full waves again, and with fewer of them.
 //
-// The recursion of PathTracer::solve (src/render.rs:136-172) is kept per lane as: the deepest
-// open hit ("current level") in registers, its ancestors in an LDS stack [slot][field][thread]
-// (global memory when max_depth is too deep for LDS).
+// Passes whose queue is short run TEAMS: T = 2..64 lanes share one pixel and trace sibling rays
+// of the open hit speculatively (see run_rounds); that shortens the per-pixel dependency chain
+// with lanes that would otherwise idle.  Radiance never depends on pass budgets or team sizes.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
@@ -27,15 +32,36 @@
 namespace rtd {
 
 #define RT_BLOCK 256
-#define RT_CHUNK 64u
-#define RT_NCLASS 3          // 0 open specular hit, 1 open diffuse hit, 2 leaf (one ray)
-#define RT_NF 19           // dwords per saved recursion level
+#define RT_NF 16             // dwords per saved recursion level
+#define RT_QHEAD 13          // dwords of a parked path before its current level
 #define RT_INVALID 0xFFFFFFFFu
+#define RT_MAX_PASSES 24
+#define RT_TRI_J 22          // candidate table: siblings j < RT_TRI_J
 
-// Everything a render / solve launch needs, passed by value (kernarg -> SGPRs).
-struct RenderParams {
+// Per-frame control block in HBM (zeroed before pass 0).
+struct PassCtl {
+    uint32_t head[RT_MAX_PASSES];        // consumption head of pass p's input
+    uint32_t count[RT_MAX_PASSES + 1];   // entries parked for pass p
+    uint32_t pad[7];
+    unsigned long long counters[4];      // [0] rays [1] samples [2] diffuse [3] specular
+};
+static_assert(sizeof(PassCtl) == 256, "PassCtl layout");
+
+// Team tables (device memory, staged in LDS by team passes).  PCG advance by k draws:
+// s' = s * mult + inc * geom.
+struct TeamTables {
+    uint64_t j2_mult[64], j2_geom[64];   // 2j draws
+    uint64_t j3_mult[64], j3_geom[64];   // 3j draws
+    uint64_t sv_mult[32], sv_geom[32];   // 2 * num_of_rays * s draws
+    uint16_t fwd[64];                    // candidate k -> sibling j | survivors s << 8 (0xFFFF: none)
+    uint8_t inv[256];                    // j*(j+1)/2 + s -> candidate k (255: none)
+};
+static_assert(sizeof(TeamTables) == 2944, "TeamTables layout");
+
+// Everything a pass needs, passed by value (kernarg -> SGPRs).
+struct PassParams {
     uint32_t n_shapes;
-    uint32_t scene_in_lds;           // 1: shapes + per-shape materials are staged in LDS
+    uint32_t mode;                   // 0: image render; 1: batch Renderer::solve on caller (ray, pcg)
     // camera (src/camera.rs)
     uint32_t cam_kind;
     float cam_distance, cam_aspect;
@@ -55,28 +81,29 @@ struct RenderParams {
     uint64_t seq_mult, seq_plus;          // master jump by 2*aa^2 draws (to the pixel's seq draw)
     // partition (row tiles dealt round-robin)
     uint32_t part, n_parts, tile_rows;
-    uint32_t n_local;                // pixels of this part
+    uint32_t n_items;                // pixels of this part / solve items
     // solve mode
     const rt_ray* in_rays;
     rt_pcg* io_pcgs;
     // outputs
     float* out;
-    uint32_t* queue_head;            // pixel-queue head (zeroed before launch)
-    // cost-ordered pixel queue built by k_classify (path tracer only; sorted == 0: identity order)
-    uint32_t sorted;
-    const uint32_t* class_counts;    // [RT_NCLASS] pixels per cost class
-    const uint32_t* order;           // [RT_NCLASS][n_local] local pixel indices of each class
-    const uint64_t* pix_mstate;      // [n_local] master PCG state at each pixel's first jitter draw
-    uint32_t idle_min;               // refill when at least this many teams of a wave are idle
-    uint64_t surv_mult[16], surv_geom[16];   // PCG advance by 2*num_of_rays*s draws, s = 0..15
-    uint32_t surv_spec;              // 1: enumerate survivor counts at the last traced level
-    // diagnostics (RUSTRACER_DEBUG_WAVES): per wave {t_start, t_end (100 MHz), rounds, active-lane rounds, refills}
-    unsigned long long* debug_waves;
-    unsigned long long* counters;    // [0] rays [1] samples [2] diffuse [3] specular
+    // pass control
+    uint32_t pass;                   // 0: fresh items; p > 0: path states parked by pass p-1
+    uint32_t budget;                 // rounds a path may run in this pass before it is parked (0: no limit)
+    uint32_t lanes_target;           // team size = lanes_target / queue length (power of two, <= max_team)
+    uint32_t max_team;
+    uint32_t idle_div;               // refill once 1/idle_div of a wave's teams are idle
+    PassCtl* ctl;
+    float* qbuf[2];                  // SoA path-state queues [field][entry]; pass p reads (p-1)&1, writes p&1
+    uint32_t q_capacity;
+    const TeamTables* tables;
     // recursion stack
     uint32_t stack_slots;            // max ancestors saved per lane
     float* gstack;                   // global stack [slot][field][global thread] when not in LDS
     uint32_t total_threads;
+    // diagnostics (RUSTRACER_DEBUG_WAVES): per pass and wave {t_start, t_end (100 MHz), rounds, active-lane rounds, team}
+    unsigned long long* debug_waves;
+    uint32_t debug_stride;           // waves per pass in debug_waves
 };
 
 // Saved level state accessors: STACK_LDS ? LDS : global.
@@ -88,10 +115,9 @@ struct LevelStack {
     __device__ __forceinline__ float ld(uint32_t slot, uint32_t f) const { return base[(slot * RT_NF + f) * stride]; }
 };
 
-
 // Master PCG of ImageTracer::all_rays at global pixel p: Pcg::new(init_state, init_seq) advanced by
 // p*(2*aa^2+1) draws (imagetracer.rs:63-81), by binary LCG jump-ahead.
-__device__ __forceinline__ uint64_t master_state_at(const RenderParams& P, uint32_t p) {
+__device__ __forceinline__ uint64_t master_state_at(const PassParams& P, uint32_t p) {
     uint64_t s = P.master_state0;
     for (uint32_t i = 0; p != 0u; ++i, p >>= 1) {
         const uint64_t s2 = s * P.pix_mult[i] + P.pix_plus[i];
@@ -101,7 +127,7 @@ __device__ __forceinline__ uint64_t master_state_at(const RenderParams& P, uint3
 }
 
 // local pixel -> global (row, col) through the row-tile partition
-__device__ __forceinline__ void local_to_global(const RenderParams& P, uint32_t q, uint32_t& grow, uint32_t& gcol) {
+__device__ __forceinline__ void local_to_global(const PassParams& P, uint32_t q, uint32_t& grow, uint32_t& gcol) {
     const uint32_t lrow = q / P.width;
     gcol = q - lrow * P.width;
     const uint32_t tile = lrow / P.tile_rows;
@@ -111,7 +137,7 @@ __device__ __forceinline__ void local_to_global(const RenderParams& P, uint32_t 
 // ImageTracer::fire_ray + Camera::fire_ray for sample `samp` of pixel (grow, gcol)
 // (imagetracer.rs:52-56, :67-75; camera.rs:68-75, :132-143); advances the master PCG by two draws.
 template <bool AFFINE>
-__device__ __forceinline__ void primary_ray(const RenderParams& P, uint32_t grow, uint32_t gcol, uint32_t samp,
+__device__ __forceinline__ void primary_ray(const PassParams& P, uint32_t grow, uint32_t gcol, uint32_t samp,
                                             uint64_t& mstate, Vec3& ro, Vec3& rd) {
     const uint32_t sub_row = samp / P.aa;
     const uint32_t sub_col = samp - sub_row * P.aa;
@@ -133,145 +159,113 @@ __device__ __forceinline__ void primary_ray(const RenderParams& P, uint32_t grow
     rd = xform_vector(P.cam_m, cdx, cdy, cdz);
 }
 
-// generate + intersect + compact (path tracer): one lane per pixel fires the pixel's first camera
-// ray, finds its closest hit and files the pixel under a cost class — open specular hit, open
-// diffuse hit, or leaf — by wave64 ballot + prefix rank, one atomic per wave and class.  k_render
-// then drains the classes heaviest first.  Also stores each pixel's master-PCG state so that the
-// render kernel does not repeat the jump-ahead.  Purely a scheduling aid: radiance never depends
-// on the order pixels are processed in.
-template <bool AFFINE>
-__global__ __launch_bounds__(RT_BLOCK) void k_classify(const RenderParams P, const DShape* __restrict__ g_shapes,
-                                                       const DMaterial* __restrict__ g_materials,
-                                                       const float* __restrict__ texels,
-                                                       uint64_t* __restrict__ pix_mstate, uint32_t* __restrict__ order,
-                                                       uint32_t* __restrict__ class_counts) {
-    const uint32_t q = blockIdx.x * RT_BLOCK + threadIdx.x;
-    const bool valid = q < P.n_local;
-    uint32_t cls = RT_NCLASS;   // none
-    if (valid) {
-        uint32_t grow, gcol;
-        local_to_global(P, q, grow, gcol);
-        uint64_t ms = master_state_at(P, grow * P.width + gcol);
-        pix_mstate[q] = ms;
-        Vec3 ro, rd;
-        primary_ray<AFFINE>(P, grow, gcol, 0u, ms, ro, rd);
-        float t;
-        const int best = closest_hit<AFFINE>(g_shapes, P.n_shapes, ro, rd, 1e-5f, __builtin_inff(), t);
-        cls = 2u;
-        if (best >= 0 && P.num_of_rays != 0u && P.max_depth >= 1u) {
-            const DShape* S = g_shapes + best;
-            const DMaterial* M = g_materials + S->material;
-            const HitRec h = hit_record<AFFINE>(S, ro, rd, t, S->needs_uv != 0u);
-            const Vec3 hc = pigment_color(&M->brdf_pigment, texels, h.u, h.v);
-            if (rt_maxf(hc.x, rt_maxf(hc.y, hc.z)) > 0.0f) cls = (M->brdf == RT_BRDF_SPECULAR) ? 0u : 1u;
-        }
-    }
-    const uint32_t lane = threadIdx.x & 63u;
-#pragma unroll
-    for (uint32_t c = 0; c < RT_NCLASS; ++c) {
-        const unsigned long long m = __ballot(cls == c);
-        if (m == 0ull) continue;
-        const uint32_t cnt = (uint32_t)__popcll(m);
-        uint32_t base = 0;
-        const uint32_t first = (uint32_t)__builtin_ctzll(m);
-        if (lane == first) base = atomicAdd(class_counts + c, cnt);
-        base = __shfl(base, first);
-        if (cls == c) {
-            const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
-            order[c * P.n_local + base + rank] = q;
-        }
-    }
+__device__ __forceinline__ uint64_t shfl_u64(uint64_t v, uint32_t src) {
+    const uint32_t lo = __shfl((uint32_t)v, src), hi = __shfl((uint32_t)(v >> 32), src);
+    return ((uint64_t)hi << 32) | lo;
 }
 
-// (A^m, sum_{j<m} A^j) for m = 0..63: per-lane PCG skip-ahead of the speculated siblings.
-struct JumpTable { uint64_t mult[64]; uint64_t geom[64]; };
-constexpr JumpTable make_jump_table() {
-    JumpTable t{};
-    uint64_t m = 1, g = 0;
-    for (int i = 0; i < 64; ++i) {
-        t.mult[i] = m;
-        t.geom[i] = g;
-        g = g * RT_PCG_MULT + 1ull;
-        m = m * RT_PCG_MULT;
-    }
-    return t;
-}
-__constant__ JumpTable c_jump = make_jump_table();
+// One node of the recursion: World::ray_intersection + the renderer's shading of the hit.
+struct NodeOut {
+    bool leaf;            // the ray returns `v` now (no open hit below it)
+    bool traced;          // World::ray_intersection was called
+    uint32_t consumed;    // PCG draws after the ray's own scatter draws
+    float vr, vg, vb;
+    // open hit (leaf == false): its children are traced in later rounds
+    Vec3 ihc, iem, iwp, icv;
+    uint32_t ibrdf;
+};
 
-// MODE 0: image render (pixel queue).  MODE 1: batch Renderer::solve on caller-supplied (ray, pcg).
-// NS > 0: the scene has exactly NS shapes (affine): the closest-hit scan is fully unrolled with the
-//         inverse matrices held in SGPRs for the whole launch.
-// T:      team size (1, 2, 4, 8, 16 lanes).  A team owns one pixel; its lanes hold identical copies
-//         of the pixel's recursion state and trace up to T SIBLING rays of the open hit per round.
-//         Sibling j's scatter draws sit at PCG offset j*(2+pred) past the level's current state
-//         provided every earlier sibling is a leaf that consumed exactly `pred` further draws
-//         (0 below the Russian-roulette depth, 1 at or beyond it).  After the round the team keeps
-//         the longest prefix for which that held (ballot + count-trailing-zeros), folds its
-//         radiances into the level in sibling order, adopts the PCG state of the last kept lane,
-//         and re-speculates the rest.  Draw order and every f32 operation equal the sequential
-//         recursion of PathTracer::solve (src/render.rs:136-172); only the latency changes.
-// The scene tables are separate __restrict__ const arguments so that wave-uniform reads of them
-// are scalar (SMEM) loads.
-template <bool AFFINE, bool STACK_LDS, int MODE, int NS, int T, int T2>
-__global__ __launch_bounds__(RT_BLOCK) void k_render(const RenderParams P, const DShape* __restrict__ g_shapes,
-                                                     const DMaterial* __restrict__ g_materials,
-                                                     const float* __restrict__ texels) {
-    static_assert(T == 1 || T == 2 || T == 4 || T == 8 || T == 16, "team size");
-    static_assert(T2 == 0 || ((T2 == 2 || T2 == 4 || T2 == 8 || T2 == 16) && T == 1 && MODE == 0 && STACK_LDS), "tail team size");
+// k_pass — one pass of the frame (see the file header).
+//
+// run_rounds<TEAMS>: TEAMS == false is one lane per pixel.  TEAMS == true: T lanes (wave-uniform power
+// of two) hold identical copies of one pixel's recursion state and trace up to T SIBLING rays of
+// the open hit per round, each under a hypothesis about the PCG draws its earlier siblings consume:
+//   * below the last traced level a sibling is assumed to be a leaf consuming `pred` draws after
+//     its two scatter draws (0 below the Russian-roulette depth, 1 at or beyond it): lane j traces
+//     sibling j at offset j*(2+pred);
+//   * at the last traced level (depth == max_depth: a hit cannot open, it consumes pred or
+//     pred + 2n draws) the team enumerates (sibling j, s of the earlier siblings survived the
+//     roulette) pairs, most probable first (TeamTables::fwd), at offset j*(2+pred) + 2n*s.
+// After the round every lane walks the siblings in order along the hypotheses that turned out
+// true, folds their radiances IN SIBLING ORDER, adopts the PCG state of the last sibling kept and
+// re-speculates the rest.  Every draw and every f32 operation equals the sequential recursion of
+// PathTracer::solve (src/render.rs:136-172); only the latency changes.
+template <bool AFFINE, bool STACK_LDS, bool SCENE_LDS>
+__global__ __launch_bounds__(RT_BLOCK) void k_pass(const PassParams P, const DScan* __restrict__ g_scan,
+                                                   const DMRows* __restrict__ g_mrows,
+                                                   const DWRows* __restrict__ g_wrows,
+                                                   const DMaterial* __restrict__ g_materials,
+                                                   const float* __restrict__ texels) {
     extern __shared__ float4 lds_raw[];
     const uint32_t tid = threadIdx.x;
     const uint32_t lane = tid & 63u;
     const uint32_t gtid = blockIdx.x * RT_BLOCK + tid;
-    constexpr bool ANY_TEAMS = (T > 1) || (T2 > 1);
 
-    // ---- LDS: [jump table (T>1)][DShape x n][DMaterial x n (one per shape)][recursion stack] ----
-    uint64_t* lds_jump = reinterpret_cast<uint64_t*>(lds_raw);
-    constexpr uint32_t JUMP_BYTES = ANY_TEAMS ? (uint32_t)sizeof(JumpTable) + 256u : 0u;   // + survivor tables
-    const bool scene_lds = (NS > 0) ? true : (P.scene_in_lds != 0u);
-    const uint32_t n_staged = scene_lds ? P.n_shapes : 0u;
-    DShape* lds_shapes = reinterpret_cast<DShape*>(reinterpret_cast<unsigned char*>(lds_raw) + JUMP_BYTES);
-    DMaterial* lds_mats = reinterpret_cast<DMaterial*>(lds_shapes + n_staged);
-    float* lds_stack = reinterpret_cast<float*>(lds_mats + n_staged);
-    if (ANY_TEAMS) {
-        const uint64_t* src = reinterpret_cast<const uint64_t*>(&c_jump);
-        for (uint32_t i = tid; i < 128u; i += RT_BLOCK) lds_jump[i] = src[i];
-        if (tid < 16u) { lds_jump[128u + tid] = P.surv_mult[tid]; lds_jump[144u + tid] = P.surv_geom[tid]; }
+    // ---- this pass's input and team size (wave-uniform, the same in every wave) ----
+    uint32_t n_in = P.n_items;
+    if (P.pass != 0u) {
+        n_in = P.ctl->count[P.pass];
+        if (n_in > P.q_capacity) n_in = P.q_capacity;
     }
-    if (scene_lds) {
-        uint32_t* dst_s = reinterpret_cast<uint32_t*>(lds_shapes);
-        const uint32_t* src_s = reinterpret_cast<const uint32_t*>(g_shapes);
-        for (uint32_t i = tid; i < n_staged * (uint32_t)(sizeof(DShape) / 4); i += RT_BLOCK) dst_s[i] = src_s[i];
+    n_in = (uint32_t)__builtin_amdgcn_readfirstlane((int)n_in);
+    if (n_in == 0u) return;
+    uint32_t T = 1u;
+    if (P.max_team > 1u) {
+        uint32_t r = P.lanes_target / n_in;
+        if (r > P.max_team) r = P.max_team;
+        while (T * 2u <= r) T *= 2u;
+    }
+    if ((uint64_t)blockIdx.x * (RT_BLOCK / T) >= (uint64_t)n_in) return;   // more blocks than work
+    const float* __restrict__ q_in = P.qbuf[(P.pass + 1u) & 1u];
+    float* __restrict__ q_out = P.qbuf[P.pass & 1u];
+    const uint32_t qcap = P.q_capacity;
+
+    // ---- LDS: [team tables][DScan x n][DMRows x n][DMaterial x n (one per shape)][recursion stack] ----
+    TeamTables* lds_tab = reinterpret_cast<TeamTables*>(lds_raw);
+    const uint32_t n_staged = SCENE_LDS ? P.n_shapes : 0u;
+    DScan* lds_scan = reinterpret_cast<DScan*>(reinterpret_cast<unsigned char*>(lds_raw) + sizeof(TeamTables));
+    DMRows* lds_mrows = reinterpret_cast<DMRows*>(lds_scan + n_staged);
+    DMaterial* lds_mats = reinterpret_cast<DMaterial*>(lds_mrows + n_staged);
+    float* lds_stack = reinterpret_cast<float*>(lds_mats + n_staged);
+    if (T > 1u) {
+        const uint32_t* src = reinterpret_cast<const uint32_t*>(P.tables);
+        uint32_t* dst = reinterpret_cast<uint32_t*>(lds_tab);
+        for (uint32_t i = tid; i < (uint32_t)(sizeof(TeamTables) / 4); i += RT_BLOCK) dst[i] = src[i];
+    }
+    if (SCENE_LDS) {
+        uint32_t* dst_s = reinterpret_cast<uint32_t*>(lds_scan);
+        const uint32_t* src_s = reinterpret_cast<const uint32_t*>(g_scan);
+        constexpr uint32_t SW = sizeof(DScan) / 4;
+        for (uint32_t i = tid; i < n_staged * SW; i += RT_BLOCK) {
+            const uint32_t sh = i / SW, j = i - sh * SW;
+            dst_s[i] = (j == 13u) ? sh : src_s[i];        // staged materials are indexed by shape
+        }
+        uint32_t* dst_r = reinterpret_cast<uint32_t*>(lds_mrows);
+        const uint32_t* src_r = reinterpret_cast<const uint32_t*>(g_mrows);
+        for (uint32_t i = tid; i < n_staged * (uint32_t)(sizeof(DMRows) / 4); i += RT_BLOCK) dst_r[i] = src_r[i];
         uint32_t* dst_m = reinterpret_cast<uint32_t*>(lds_mats);
         constexpr uint32_t MW = sizeof(DMaterial) / 4;
         for (uint32_t i = tid; i < n_staged * MW; i += RT_BLOCK) {
             const uint32_t sh = i / MW, j = i - sh * MW;
-            dst_m[i] = reinterpret_cast<const uint32_t*>(g_materials + g_shapes[sh].material)[j];
+            dst_m[i] = reinterpret_cast<const uint32_t*>(g_materials + g_scan[sh].material)[j];
         }
     }
-    if (ANY_TEAMS || scene_lds) __syncthreads();
+    if (T > 1u || SCENE_LDS) __syncthreads();
+    const DScan* __restrict__ scan = SCENE_LDS ? lds_scan : g_scan;
+    const DMRows* __restrict__ mrows = SCENE_LDS ? lds_mrows : g_mrows;
+    const DMaterial* __restrict__ mats = SCENE_LDS ? lds_mats : g_materials;
 
     LevelStack<STACK_LDS> stack;
     if (STACK_LDS) { stack.base = lds_stack + tid; stack.stride = RT_BLOCK; }
     else { stack.base = P.gstack + gtid; stack.stride = P.total_threads; }
 
-    // NS > 0: inverse matrices (rows 0..2) and kinds of all NS shapes, wave-uniform for the launch
-    float sinv[NS > 0 ? NS : 1][12];
-    uint32_t skind[NS > 0 ? NS : 1];
-    if (NS > 0) {
-#pragma unroll
-        for (int i = 0; i < NS; ++i) {
-#pragma unroll
-            for (int j = 0; j < 12; ++j)
-                sinv[i][j] = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(g_shapes[i].inv[j])));
-            skind[i] = __builtin_amdgcn_readfirstlane(g_shapes[i].kind);
-        }
-    }
-
     const uint32_t aa2 = P.aa * P.aa;
     const uint32_t n_children = P.num_of_rays;
+    const uint32_t n_qfields = RT_QHEAD + RT_NF * (1u + P.stack_slots);
+    (void)n_qfields;
 
-    // ---- team state, replicated in every lane of the team ----
-    uint32_t q = RT_INVALID;        // local pixel (MODE 0) / batch index (MODE 1) owned by the team
+    // ---- path state, replicated in every lane of the team ----
+    uint32_t q = RT_INVALID;        // local pixel (mode 0) / batch index (mode 1) owned by the team
     uint32_t samp = 0;              // samples of q already started
     uint64_t mstate = 0;            // master PCG state at the next jitter draw of q
     uint64_t pstate = 0, pinc = 1;  // the pixel's PCG (state before this round's draws)
@@ -282,50 +276,132 @@ __global__ __launch_bounds__(RT_BLOCK) void k_render(const RenderParams P, const
     float rtmin = 1e-5f, rtmax = __builtin_inff();
     uint32_t lvl = 0;               // recursion level of the rays traced next (0 = the level-0 ray)
     uint32_t base_depth = 0;        // Ray.depth of the level-0 ray
+    uint32_t rounds_left = 0;       // of this pass's budget
     // current level = the open hit at level lvl-1
     float hc_r = 0.f, hc_g = 0.f, hc_b = 0.f, em_r = 0.f, em_g = 0.f, em_b = 0.f;
     float cu_r = 0.f, cu_g = 0.f, cu_b = 0.f;
     uint32_t kcount = 0, cur_brdf = 0;   // kcount: children of the current level already started
-    Vec3 cw = {0.f, 0.f, 0.f}, cn = {0.f, 0.f, 1.f}, cin = {1.f, 0.f, 0.f};
+    Vec3 cw = {0.f, 0.f, 0.f};           // hit.world_point
+    Vec3 cv = {0.f, 0.f, 1.f};           // diffuse: hit.normal (raw); specular: the mirrored direction
     // counters (kept by the team leader)
     uint32_t n_rays = 0, n_samples = 0, n_diffuse = 0, n_specular = 0;
 
-    // wave-private slice of the pixel queue
+    // wave-private slice of the input queue
     uint32_t wcur = 0, wend = 0;
     bool exhausted = false;
-    uint32_t dbg_pix_rounds = 0, dbg_max_pix_rounds = 0;
     // diagnostics
     unsigned long long dbg_t0 = 0;
     uint32_t dbg_rounds = 0, dbg_lanes = 0;
     if (P.debug_waves) dbg_t0 = __builtin_amdgcn_s_memrealtime();
-    // cost-ordered queue: position h of the concatenated class lists -> local pixel
-    uint32_t cls_end0 = 0, cls_end1 = 0;
-    if (MODE == 0 && P.sorted) {
-        cls_end0 = P.class_counts[0];
-        cls_end1 = cls_end0 + P.class_counts[1];
-    }
+    // section cycle counters (diagnostics): 0 generate 1 scatter 2 scan 3 hit+shade 4 resolve 5 park
+    uint32_t dbg_sec[6] = {0, 0, 0, 0, 0, 0};
+    uint64_t dbg_prev = 0;
+#define RT_DBG_MARK(i) do { if (P.debug_waves) { const uint64_t now_ = __builtin_readcyclecounter(); dbg_sec[i] += (uint32_t)(now_ - dbg_prev); dbg_prev = now_; } } while (0)
 
-    // The round loop, instantiated per team size TT.  stop_live > 0: return true (instead of running
-    // to completion) once the queue is exhausted and at most stop_live pixels are left in the wave.
-    auto run_rounds = [&](auto team_tag, const uint32_t stop_live) -> bool {
-    constexpr int TT = decltype(team_tag)::value;
-    const uint32_t jj = (TT > 1) ? (lane & (uint32_t)(TT - 1)) : 0u;   // candidate slot of this lane
-    const uint32_t team0 = lane & ~(uint32_t)(TT - 1);                 // first lane of the team
+    // ---------------------------------------------------------------------------------------------
+    // one node: intersect + shade (render.rs:57-67, :76-89, :136-171)
+    // ---------------------------------------------------------------------------------------------
+    auto trace_node = [&](const Vec3 o, const Vec3 d, const float tmin, const float tmax, const uint32_t depth,
+                          uint64_t& st, NodeOut& R) {
+        R.leaf = true; R.traced = false; R.consumed = 0u;
+        R.vr = 0.f; R.vg = 0.f; R.vb = 0.f;
+        if (P.algorithm == RT_ALGO_DUMMY) {
+            R.vr = 1.0f; R.vg = 2.0f; R.vb = 3.0f;   // render.rs:180-185
+            return;
+        }
+        if (P.algorithm == RT_ALGO_PATHTRACER && depth > P.max_depth) return;   // render.rs:137-139
+        float t;
+        const int best = scan_closest_hit<AFFINE>(scan, g_wrows, P.n_shapes, o, d, tmin, tmax, t);
+        R.traced = true;
+        RT_DBG_MARK(2);
+        if (best < 0) {
+            R.vr = P.bg[0]; R.vg = P.bg[1]; R.vb = P.bg[2];
+            return;
+        }
+        if (P.algorithm == RT_ALGO_ONOFF) {
+            R.vr = P.fg[0]; R.vg = P.fg[1]; R.vb = P.fg[2];   // render.rs:61-66
+            return;
+        }
+        const DScan* S = scan + best;
+        const DMaterial* M = mats + S->material;
+        const bool can_open = (P.algorithm == RT_ALGO_PATHTRACER) && (depth + 1u <= P.max_depth);
+        const HitRec h = scan_hit_record<AFFINE>(S, mrows + best, g_wrows + best, o, d, t, S->needs_uv != 0u, can_open);
+        Vec3 hc = pigment_color(&M->brdf_pigment, texels, h.u, h.v);
+        const Vec3 em = pigment_color(&M->emitted, texels, h.u, h.v);
+        if (P.algorithm == RT_ALGO_FLAT) {
+            R.vr = em.x + hc.x; R.vg = em.y + hc.y; R.vb = em.z + hc.z;   // render.rs:83-84
+            return;
+        }
+        // PathTracer::solve (render.rs:146-171)
+        const float lum = rt_maxf(hc.x, rt_maxf(hc.y, hc.z));
+        if (depth >= P.rr_limit) {
+            const float rq = rt_maxf(1.0f - lum, 0.05f);
+            R.consumed = 1u;
+            if (pcg_random_float(st, pinc) > rq) {
+                const float s = 1.0f / (1.0f - rq);
+                hc.x = hc.x * s; hc.y = hc.y * s; hc.z = hc.z * s;
+            } else {
+                R.vr = em.x; R.vg = em.y; R.vb = em.z;
+                return;
+            }
+        }
+        if (lum > 0.0f && n_children != 0u) {
+            if (!can_open) {
+                // every child returns black without an intersection (render.rs:137-139) but its
+                // two scatter draws are consumed (render.rs:161).
+                st = st * P.skip_mult + pinc * P.skip_plus;
+                R.consumed += 2u * n_children;
+                const float cr = 0.0f + hc.x * 0.0f, cg = 0.0f + hc.y * 0.0f, cb = 0.0f + hc.z * 0.0f;
+                R.vr = em.x + cr * P.inv_num_of_rays;
+                R.vg = em.y + cg * P.inv_num_of_rays;
+                R.vb = em.z + cb * P.inv_num_of_rays;
+            } else {
+                R.leaf = false;
+                R.ihc = hc; R.iem = em; R.iwp = h.world_point;
+                R.ibrdf = M->brdf;
+                // SpecularBRDF::scatter_ray ignores its draws: every child of this hit has the same
+                // direction, computed once from hit.ray.dir and hit.normal (material.rs:225-246)
+                if (R.ibrdf == RT_BRDF_SPECULAR) R.icv = specular_scatter_dir(d, h.normal);
+                else R.icv = h.normal;
+            }
+        } else {
+            // no children: emitted + 0 * (1/n) (render.rs:157, :171)
+            R.vr = em.x + 0.0f * P.inv_num_of_rays;
+            R.vg = em.y + 0.0f * P.inv_num_of_rays;
+            R.vb = em.z + 0.0f * P.inv_num_of_rays;
+        }
+    };
+
+    // ---------------------------------------------------------------------------------------------
+    // the round loop
+    // ---------------------------------------------------------------------------------------------
+    auto run_rounds = [&](auto teams_tag) {
+    constexpr bool TEAMS = decltype(teams_tag)::value;
+    const uint32_t TT = TEAMS ? T : 1u;
+    const uint32_t jj = TEAMS ? (lane & (TT - 1u)) : 0u;       // candidate slot of this lane
+    const uint32_t team0 = TEAMS ? (lane & ~(TT - 1u)) : lane; // first lane of the team
     const bool leader = (jj == 0u);
+    const unsigned long long tmask = (TT >= 64u) ? ~0ull : ((1ull << TT) - 1ull);
+    const uint32_t n_teams = 64u / TT;
+    uint32_t idle_min = n_teams / P.idle_div;
+    if (idle_min < 1u) idle_min = 1u;
+
+    if (P.debug_waves) dbg_prev = __builtin_readcyclecounter();
     for (;;) {
         // =====================================================================================
-        // generate / compact: teams without a solve in flight take the next sample or pixel
+        // generate / compact in: teams without a solve in flight retire their pixel, take the
+        // next sample, or take a new entry of the pass's queue
         // =====================================================================================
         const unsigned long long idle_leaders = __ballot(!busy && leader);
         const unsigned long long busy_any = __ballot(busy);
-        if (idle_leaders != 0ull && ((uint32_t)__popcll(idle_leaders) >= P.idle_min || busy_any == 0ull)) {
-            bool want_pixel = false;
+        if (idle_leaders != 0ull && ((uint32_t)__popcll(idle_leaders) >= idle_min || busy_any == 0ull)) {
+            bool want = false;
             if (!busy) {
                 if (q != RT_INVALID && samp == aa2) {
                     // pixel (or solve item) finished: color * (1 / aa^2)  (imagetracer.rs:121)
                     if (leader) {
                         float* o = P.out + 3ull * q;
-                        if (MODE == 0) {
+                        if (P.mode == 0u) {
                             o[0] = acc_r * P.inv_samples;
                             o[1] = acc_g * P.inv_samples;
                             o[2] = acc_b * P.inv_samples;
@@ -335,69 +411,83 @@ __global__ __launch_bounds__(RT_BLOCK) void k_render(const RenderParams P, const
                         }
                     }
                     q = RT_INVALID;
-                    if (dbg_pix_rounds > dbg_max_pix_rounds) dbg_max_pix_rounds = dbg_pix_rounds;
-                    dbg_pix_rounds = 0;
                 }
-                want_pixel = (q == RT_INVALID) && !exhausted;
+                want = (q == RT_INVALID) && !exhausted;
             }
             // wave64 ballot + prefix rank hand out consecutive queue entries to the idle teams
-            unsigned long long wantmask = __ballot(want_pixel && leader);
-            bool newpix = false;
-            bool lead_want = want_pixel && leader;
+            bool lead_want = want && leader;
+            unsigned long long wantmask = __ballot(lead_want);
+            uint32_t h = RT_INVALID;
             while (wantmask != 0ull) {
                 if (wcur == wend) {
-                    // heavy classes are handed out in small chunks (longest-processing-time first)
-                    constexpr uint32_t TEAMS = 64u / (uint32_t)TT;     // pixels a wave holds at once
-                    uint32_t chunk = TEAMS;
-                    if (P.sorted) {
-                        chunk = (wend < cls_end0) ? 4u : (wend < cls_end1) ? 16u : RT_CHUNK;
-                        if (chunk > TEAMS) chunk = TEAMS;
-                    }
                     uint32_t b = 0;
-                    if (lane == 0) b = atomicAdd(P.queue_head, chunk);
+                    if (lane == 0) b = atomicAdd(&P.ctl->head[P.pass], n_teams);
                     b = __shfl(b, 0);
-                    if (b >= P.n_local) { exhausted = true; break; }
+                    if (b >= n_in) { exhausted = true; break; }
                     wcur = b;
-                    wend = (b + chunk < P.n_local) ? b + chunk : P.n_local;
+                    wend = (b + n_teams < n_in) ? b + n_teams : n_in;
                 }
                 const uint32_t avail = wend - wcur;
                 const uint32_t wanted = (uint32_t)__popcll(wantmask);
                 const uint32_t cnt = wanted < avail ? wanted : avail;
                 const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(wantmask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)wantmask, 0u));
                 if (lead_want && rank < cnt) {
-                    const uint32_t h = wcur + rank;
-                    q = h;
-                    if (MODE == 0 && P.sorted) {
-                        if (h < cls_end0) q = P.order[h];
-                        else if (h < cls_end1) q = P.order[P.n_local + (h - cls_end0)];
-                        else q = P.order[2u * P.n_local + (h - cls_end1)];
-                    }
+                    h = wcur + rank;
                     lead_want = false;
-                    newpix = true;
                 }
                 wcur += cnt;
                 wantmask = __ballot(lead_want);
             }
-            if (TT > 1) {
-                q = __shfl(q, team0);
-                newpix = __shfl((int)newpix, team0) != 0;
-            }
-            if (!busy && q != RT_INVALID) {
-                if (MODE == 0) {
-                    if (newpix) {
+            if (TEAMS) h = __shfl(h, team0);
+            if (!busy && h != RT_INVALID) {
+                rounds_left = P.budget;
+                if (P.pass == 0u) {
+                    q = h;
+                    samp = 0;
+                    acc_r = 0.f; acc_g = 0.f; acc_b = 0.f;
+                    lvl = 0;
+                    if (P.mode == 0u) {
                         local_to_global(P, q, grow, gcol);
                         // master PCG at this pixel: jump ahead p*(2*aa^2+1) draws (imagetracer.rs:63-81)
-                        uint64_t s;
-                        if (P.sorted) s = P.pix_mstate[q];
-                        else s = master_state_at(P, grow * P.width + gcol);
+                        const uint64_t s = master_state_at(P, grow * P.width + gcol);
                         mstate = s;
                         // seq = the u32 drawn after the pixel's 2*aa^2 jitter draws (imagetracer.rs:79)
                         const uint64_t sq = s * P.seq_mult + P.seq_plus;
                         const uint64_t seq = (uint64_t)pcg_output(sq);
                         pcg_new(P.init_state, seq, pstate, pinc);   // imagetracer.rs:117
-                        samp = 0;
-                        acc_r = 0.f; acc_g = 0.f; acc_b = 0.f;
                     }
+                } else {
+                    // a path parked by the previous pass
+                    const float* e = q_in + h;
+                    q = __float_as_uint(e[0ull * qcap]);
+                    samp = __float_as_uint(e[1ull * qcap]);
+                    lvl = __float_as_uint(e[2ull * qcap]);
+                    base_depth = __float_as_uint(e[3ull * qcap]);
+                    mstate = (uint64_t)__float_as_uint(e[4ull * qcap]) | ((uint64_t)__float_as_uint(e[5ull * qcap]) << 32);
+                    pstate = (uint64_t)__float_as_uint(e[6ull * qcap]) | ((uint64_t)__float_as_uint(e[7ull * qcap]) << 32);
+                    pinc = (uint64_t)__float_as_uint(e[8ull * qcap]) | ((uint64_t)__float_as_uint(e[9ull * qcap]) << 32);
+                    acc_r = e[10ull * qcap]; acc_g = e[11ull * qcap]; acc_b = e[12ull * qcap];
+                    if (P.mode == 0u) local_to_global(P, q, grow, gcol);
+                    if (lvl > 0u) {
+                        const float* c = e + (uint64_t)RT_QHEAD * qcap;
+                        hc_r = c[0ull * qcap]; hc_g = c[1ull * qcap]; hc_b = c[2ull * qcap];
+                        em_r = c[3ull * qcap]; em_g = c[4ull * qcap]; em_b = c[5ull * qcap];
+                        cu_r = c[6ull * qcap]; cu_g = c[7ull * qcap]; cu_b = c[8ull * qcap];
+                        cw.x = c[9ull * qcap]; cw.y = c[10ull * qcap]; cw.z = c[11ull * qcap];
+                        cv.x = c[12ull * qcap]; cv.y = c[13ull * qcap]; cv.z = c[14ull * qcap];
+                        const uint32_t kb = __float_as_uint(c[15ull * qcap]);
+                        kcount = kb >> 1;
+                        cur_brdf = kb & 1u;
+                        const uint32_t n_saved = (lvl - 1u) * RT_NF;
+                        const float* sv = c + (uint64_t)RT_NF * qcap;
+                        for (uint32_t i = 0; i < n_saved; ++i) stack.base[i * stack.stride] = sv[(uint64_t)i * qcap];
+                        busy = true;
+                    }
+                }
+            }
+            if (!busy && q != RT_INVALID) {
+                // start the next top-level solve of q (imagetracer.rs:118-120)
+                if (P.mode == 0u) {
                     primary_ray<AFFINE>(P, grow, gcol, samp, mstate, ro, rd);
                     rtmin = 1e-5f;
                     rtmax = __builtin_inff();
@@ -411,8 +501,6 @@ __global__ __launch_bounds__(RT_BLOCK) void k_render(const RenderParams P, const
                     base_depth = r.depth;
                     pstate = P.io_pcgs[q].state;
                     pinc = P.io_pcgs[q].inc;
-                    samp = 0;
-                    acc_r = 0.f; acc_g = 0.f; acc_b = 0.f;
                 }
                 samp += 1;
                 if (leader) n_samples += 1;
@@ -420,227 +508,114 @@ __global__ __launch_bounds__(RT_BLOCK) void k_render(const RenderParams P, const
                 busy = true;
             }
         }
-        if (__ballot(busy) == 0ull) return false;  // queue empty and every team retired
-        if (stop_live != 0u && exhausted) {
-            const uint32_t live = (uint32_t)__popcll(__ballot(busy || (q != RT_INVALID && samp < aa2)));
-            if (live <= stop_live) return true;
-        }
+        if (__ballot(busy) == 0ull) break;  // queue empty and every team retired or parked
+        RT_DBG_MARK(0);
+
         // =====================================================================================
-        // this round's candidate rays: the level-0 ray, or up to T siblings of the open hit
+        // this round's candidate rays: the level-0 ray, or siblings of the open hit
         // =====================================================================================
         const uint32_t depth = base_depth + lvl;     // Ray.depth of the rays traced this round
-        // Candidate (cj, cs) of this lane: sibling kcount+cj, assuming cs of the earlier siblings of this
-        // round consumed the long draw count.  Below the last traced level cs = 0 and cj = jj.  At the
-        // last level (depth == max_depth: a hit cannot open, it consumes pred or pred + 2n draws) the
-        // team enumerates all (cj, cs <= cj) in triangular order, so several siblings resolve per round
-        // whatever their roulette outcomes were.
-        const bool last_level = (TT > 1) && (lvl > 0u) && (depth == P.max_depth) && (P.surv_spec != 0u);
-        uint32_t cj = jj, cs = 0u;
-        if (last_level) {
-            cj = (jj >= 15u) ? 5u : (jj >= 10u) ? 4u : (jj >= 6u) ? 3u : (jj >= 3u) ? 2u : (jj >= 1u) ? 1u : 0u;
-            cs = jj - ((cj * (cj + 1u)) >> 1);
+        // draws an earlier sibling is assumed to consume after its two scatter draws
+        const uint32_t pred = (lvl > 0u && depth >= P.rr_limit) ? 1u : 0u;
+        const bool last_level = TEAMS && (lvl > 0u) && (depth == P.max_depth);
+        uint32_t cj = jj, cs = 0u;   // this lane's candidate: sibling kcount+cj, cs earlier survivors
+        if (TEAMS && last_level) {
+            const uint32_t fw = lds_tab->fwd[jj];
+            cj = fw & 0xFFu;
+            cs = fw >> 8;
         }
         uint32_t n_rem = 0;          // rays this level still has to start
         if (busy) n_rem = (lvl == 0u) ? 1u : (n_children - kcount);
         const bool act = busy && ((lvl == 0u) ? (jj == 0u) : (cj < n_rem));
-        if (P.debug_waves) {
-            dbg_rounds += 1u; dbg_lanes += (uint32_t)__popcll(__ballot(act));
-            if (busy) dbg_pix_rounds += 1u;
-        }
-        // draws an earlier sibling is assumed to consume after its two scatter draws
-        const uint32_t pred = (lvl > 0u && depth >= P.rr_limit) ? 1u : 0u;
+        if (P.debug_waves) { dbg_rounds += 1u; dbg_lanes += (uint32_t)__popcll(__ballot(act)); }
 
         uint64_t st = pstate;        // this lane's PCG, advanced through its own ray's draws
-        bool leaf = true;            // the ray returns a value this round (no open hit below it)
-        bool traced = false;         // World::ray_intersection was called
-        uint32_t consumed = 0;       // draws after the scatter draws
-        float vr = 0.f, vg = 0.f, vb = 0.f;
-        // open-hit data if !leaf
-        Vec3 ihc = {0.f, 0.f, 0.f}, iem = {0.f, 0.f, 0.f}, iwp = {0.f, 0.f, 0.f}, inr = {0.f, 0.f, 1.f};
-        Vec3 idir = {1.f, 0.f, 0.f};
-        uint32_t ibrdf = 0;
-
+        NodeOut R;
+        R.leaf = true; R.traced = false; R.consumed = 0u;
+        R.vr = 0.f; R.vg = 0.f; R.vb = 0.f;
+        R.ihc = {0.f, 0.f, 0.f}; R.iem = {0.f, 0.f, 0.f}; R.iwp = {0.f, 0.f, 0.f}; R.icv = {0.f, 0.f, 1.f};
+        R.ibrdf = 0u;
         if (act) {
             Vec3 o, d;
             float tmin, tmax;
             if (lvl == 0u) {
                 o = ro; d = rd; tmin = rtmin; tmax = rtmax;
             } else {
-                // BRDF::scatter_ray of sibling kcount+jj (render.rs:160-166)
-                if (TT > 1) {
-                    const uint32_t m = cj * (2u + pred);
-                    st = st * lds_jump[m] + pinc * lds_jump[64u + m];
-                    if (last_level) st = st * lds_jump[128u + cs] + pinc * lds_jump[144u + cs];
+                // BRDF::scatter_ray of this lane's sibling (render.rs:160-166)
+                if (TEAMS) {
+                    if (pred) st = st * lds_tab->j3_mult[cj] + pinc * lds_tab->j3_geom[cj];
+                    else st = st * lds_tab->j2_mult[cj] + pinc * lds_tab->j2_geom[cj];
+                    if (last_level) st = st * lds_tab->sv_mult[cs] + pinc * lds_tab->sv_geom[cs];
                 }
                 const float rf0 = pcg_random_float(st, pinc);
                 const float rf1 = pcg_random_float(st, pinc);
                 if (cur_brdf == RT_BRDF_DIFFUSE) {
-                    d = diffuse_scatter_dir(rf0, rf1, cn);
+                    d = diffuse_scatter_dir(rf0, rf1, cv);
                     tmin = 1.0e-3f;                   // material.rs:181
                 } else {
-                    d = specular_scatter_dir(cin, cn);
+                    d = cv;
                     tmin = 1e-5f;                     // Ray::default (ray.rs:50)
                 }
                 o = cw;
                 tmax = __builtin_inff();
             }
-
-            // ---- intersect + shade one node ----
-            if (P.algorithm == RT_ALGO_DUMMY) {
-                vr = 1.0f; vg = 2.0f; vb = 3.0f;   // render.rs:180-185
-            } else if (P.algorithm == RT_ALGO_PATHTRACER && depth > P.max_depth) {
-                // render.rs:137-139 (only reachable for a caller-supplied deep ray)
-            } else {
-                float t;
-                int best;
-                if (NS > 0) {
-                    best = -1;
-                    t = 0.0f;
-#pragma unroll
-                    for (int i = 0; i < NS; ++i) {
-                        const Vec3 so = xform_point<true>(sinv[i], o.x, o.y, o.z);
-                        const Vec3 sd = xform_vector(sinv[i], d.x, d.y, d.z);
-                        float ti = 0.0f;
-                        bool hit;
-                        if (skind[i] == RT_SHAPE_SPHERE) hit = sphere_t(so, sd, tmin, tmax, ti);
-                        else hit = plane_t(so, sd, tmin, tmax, ti);
-                        if (hit && (best < 0 || ti < t)) { best = i; t = ti; }
-                    }
-                } else {
-                    best = closest_hit<AFFINE>(g_shapes, P.n_shapes, o, d, tmin, tmax, t);
-                }
-                traced = true;
-                if (best < 0) {
-                    vr = P.bg[0]; vg = P.bg[1]; vb = P.bg[2];
-                } else if (P.algorithm == RT_ALGO_ONOFF) {
-                    vr = P.fg[0]; vg = P.fg[1]; vb = P.fg[2];   // render.rs:61-66
-                } else {
-                    const DShape* S;
-                    const DMaterial* M;
-                    if (scene_lds) { S = lds_shapes + best; M = lds_mats + best; }
-                    else { S = g_shapes + best; M = g_materials + S->material; }
-                    const bool want_uv = S->needs_uv != 0u;
-                    const HitRec h = hit_record<AFFINE>(S, o, d, t, want_uv);
-                    Vec3 hc = pigment_color(&M->brdf_pigment, texels, h.u, h.v);
-                    const Vec3 em = pigment_color(&M->emitted, texels, h.u, h.v);
-                    if (P.algorithm == RT_ALGO_FLAT) {
-                        vr = em.x + hc.x; vg = em.y + hc.y; vb = em.z + hc.z;   // render.rs:83-84
-                    } else {
-                        // PathTracer::solve (render.rs:146-171)
-                        const float lum = rt_maxf(hc.x, rt_maxf(hc.y, hc.z));
-                        bool alive = true;
-                        if (depth >= P.rr_limit) {
-                            const float rq = rt_maxf(1.0f - lum, 0.05f);
-                            consumed = 1u;
-                            if (pcg_random_float(st, pinc) > rq) {
-                                const float s = 1.0f / (1.0f - rq);
-                                hc.x = hc.x * s; hc.y = hc.y * s; hc.z = hc.z * s;
-                            } else {
-                                vr = em.x; vg = em.y; vb = em.z;
-                                alive = false;
-                            }
-                        }
-                        if (alive) {
-                            if (lum > 0.0f && n_children != 0u) {
-                                if (depth + 1u > P.max_depth) {
-                                    // every child returns black without an intersection (render.rs:137-139)
-                                    // but its two scatter draws are consumed (render.rs:161).
-                                    st = st * P.skip_mult + pinc * P.skip_plus;
-                                    consumed += 2u * n_children;
-                                    const float cr = 0.0f + hc.x * 0.0f, cg = 0.0f + hc.y * 0.0f, cb = 0.0f + hc.z * 0.0f;
-                                    vr = em.x + cr * P.inv_num_of_rays;
-                                    vg = em.y + cg * P.inv_num_of_rays;
-                                    vb = em.z + cb * P.inv_num_of_rays;
-                                } else {
-                                    // an open hit: its children are traced in later rounds
-                                    leaf = false;
-                                    ihc = hc; iem = em; iwp = h.world_point; inr = h.normal;
-                                    idir = d;          // hit.ray.dir (render.rs:162)
-                                    ibrdf = M->brdf;
-                                }
-                            } else {
-                                // no children: emitted + 0 * (1/n) (render.rs:157, :171)
-                                vr = em.x + 0.0f * P.inv_num_of_rays;
-                                vg = em.y + 0.0f * P.inv_num_of_rays;
-                                vb = em.z + 0.0f * P.inv_num_of_rays;
-                            }
-                        }
-                    }
-                }
-            }
+            RT_DBG_MARK(1);
+            trace_node(o, d, tmin, tmax, depth, st, R);
         }
+        RT_DBG_MARK(3);
 
         // =====================================================================================
-        // resolve: keep the longest prefix of siblings whose PCG offsets were right
+        // resolve: walk the siblings in order along the hypotheses that held, fold their radiances
         // =====================================================================================
-        if (busy) {
-            uint32_t n_valid = 1u, last = 0u;
-            bool last_leaf = leaf;
-            uint32_t traced_valid = traced ? 1u : 0u;
-            // fold the kept leaves into the level, in sibling order (render.rs:168 / imagetracer.rs:119)
-            float pr, pg, pb;
-            if (lvl == 0u) { pr = vr; pg = vg; pb = vb; }
-            else { pr = hc_r * vr; pg = hc_g * vg; pb = hc_b * vb; }
-            float tr = (lvl == 0u) ? acc_r : cu_r, tg = (lvl == 0u) ? acc_g : cu_g, tb_ = (lvl == 0u) ? acc_b : cu_b;
-            if (TT > 1) {
-                constexpr uint32_t tmask = (1u << TT) - 1u;
-                const uint32_t b_leaf = (uint32_t)(__ballot(act && leaf) >> team0) & tmask;
-                const uint32_t b_traced = (uint32_t)(__ballot(traced) >> team0) & tmask;
-                if (!last_level) {
-                    // linear layout: keep siblings up to and including the first that is not a
-                    // leaf with the predicted draw count
-                    const bool bad = act && !(leaf && (lvl == 0u || consumed == pred));
-                    const uint32_t tb = (uint32_t)(__ballot(bad) >> team0) & tmask;
-                    uint32_t n_cand = n_rem < (uint32_t)TT ? n_rem : (uint32_t)TT;
-                    const uint32_t first_bad = tb ? (uint32_t)__builtin_ctz(tb) : n_cand;
-                    n_valid = first_bad + 1u < n_cand ? first_bad + 1u : n_cand;
-                    last = n_valid - 1u;
-                    last_leaf = ((b_leaf >> last) & 1u) != 0u;
-                    traced_valid = (uint32_t)__popc(b_traced & ((1u << n_valid) - 1u));
-                    const uint32_t n_acc = n_valid - (last_leaf ? 0u : 1u);
-#pragma unroll
-                    for (int i = 0; i < TT; ++i) {
-                        const float qr = __shfl(pr, team0 + i), qg = __shfl(pg, team0 + i), qb = __shfl(pb, team0 + i);
-                        if ((uint32_t)i < n_acc) { tr = tr + qr; tg = tg + qg; tb_ = tb_ + qb; }
-                    }
-                } else {
-                    // triangular layout: walk the siblings in order, following the survivor count
-                    constexpr int JM = (TT >= 16) ? 6 : (TT >= 8) ? 4 : (TT >= 4) ? 3 : 2;
-                    const uint32_t b_act = (uint32_t)(__ballot(act) >> team0) & tmask;
-                    const uint32_t b_lo = (uint32_t)(__ballot(act && leaf && consumed == pred) >> team0) & tmask;
-                    const uint32_t b_hi = (uint32_t)(__ballot(act && leaf && consumed == pred + 2u * n_children) >> team0) & tmask;
-                    uint32_t ch[JM];
-                    uint32_t surv = 0u;
-                    bool cont = true;
-                    n_valid = 0u;
-                    traced_valid = 0u;
-#pragma unroll
-                    for (int j = 0; j < JM; ++j) {
-                        const uint32_t idx = (uint32_t)((j * (j + 1)) >> 1) + surv;
-                        const bool ok = cont && idx < (uint32_t)TT && ((b_act >> idx) & 1u) != 0u;
-                        ch[j] = idx < (uint32_t)TT ? idx : 0u;
-                        if (ok) {
-                            n_valid = (uint32_t)j + 1u;
-                            last = idx;
-                            traced_valid += (b_traced >> idx) & 1u;
-                        }
-                        const bool hi = ((b_hi >> idx) & 1u) != 0u;
-                        cont = ok && ((((b_lo >> idx) & 1u) != 0u) || hi);
-                        if (ok && hi) surv += 1u;
-                    }
-                    last_leaf = ((b_leaf >> last) & 1u) != 0u;
-                    const uint32_t n_acc = n_valid - (last_leaf ? 0u : 1u);
-#pragma unroll
-                    for (int j = 0; j < JM; ++j) {
-                        const float qr = __shfl(pr, team0 + ch[j]), qg = __shfl(pg, team0 + ch[j]), qb = __shfl(pb, team0 + ch[j]);
-                        if ((uint32_t)j < n_acc) { tr = tr + qr; tg = tg + qg; tb_ = tb_ + qb; }
-                    }
+        float pr, pg, pb;
+        if (lvl == 0u) { pr = R.vr; pg = R.vg; pb = R.vb; }
+        else { pr = hc_r * R.vr; pg = hc_g * R.vg; pb = hc_b * R.vb; }   // render.rs:168
+        float tr = (lvl == 0u) ? acc_r : cu_r, tg = (lvl == 0u) ? acc_g : cu_g, tb_ = (lvl == 0u) ? acc_b : cu_b;
+        uint32_t n_valid = 1u, last = 0u, traced_valid = R.traced ? 1u : 0u;
+        bool last_leaf = R.leaf;
+        uint64_t nstate = st;
+        if (TEAMS) {
+            const unsigned long long b_act = (__ballot(act) >> team0) & tmask;
+            const unsigned long long b_leaf = (__ballot(act && R.leaf) >> team0) & tmask;
+            const unsigned long long b_traced = (__ballot(R.traced) >> team0) & tmask;
+            const unsigned long long b_lo = (__ballot(act && R.leaf && (lvl == 0u || R.consumed == pred)) >> team0) & tmask;
+            const unsigned long long b_hi = (__ballot(act && R.leaf && last_level && R.consumed == pred + 2u * n_children) >> team0) & tmask;
+            uint32_t surv = 0u, j = 0u;
+            bool cont = busy;            // sibling j of this round is on the true path
+            n_valid = 0u; traced_valid = 0u;
+            while (__ballot(cont) != 0ull) {
+                uint32_t idx = j;
+                if (last_level) idx = (j < RT_TRI_J) ? (uint32_t)lds_tab->inv[((j * (j + 1u)) >> 1) + surv] : 255u;
+                const bool ok = cont && idx < TT && ((b_act >> idx) & 1ull) != 0ull;
+                const uint32_t src = team0 + (ok ? idx : 0u);
+                const float qr = __shfl(pr, src), qg = __shfl(pg, src), qb = __shfl(pb, src);
+                if (ok) {
+                    n_valid = j + 1u;
+                    last = idx;
+                    traced_valid += (uint32_t)((b_traced >> idx) & 1ull);
+                    if ((b_leaf >> idx) & 1ull) { tr = tr + qr; tg = tg + qg; tb_ = tb_ + qb; }
                 }
-                pstate = __shfl(st, team0 + last);
-            } else {
-                if (last_leaf) { tr = tr + pr; tg = tg + pg; tb_ = tb_ + pb; }
-                pstate = st;
+                const bool hi = ok && ((b_hi >> idx) & 1ull) != 0ull;
+                cont = ok && (hi || ((b_lo >> idx) & 1ull) != 0ull);
+                if (hi) surv += 1u;
+                j += 1u;
             }
+            last_leaf = ((b_leaf >> last) & 1ull) != 0ull;
+            nstate = shfl_u64(st, team0 + last);
+            // open-hit data of the last sibling kept
+            if (__ballot(busy && !last_leaf) != 0ull) {
+                const uint32_t src = team0 + last;
+                R.ihc.x = __shfl(R.ihc.x, src); R.ihc.y = __shfl(R.ihc.y, src); R.ihc.z = __shfl(R.ihc.z, src);
+                R.iem.x = __shfl(R.iem.x, src); R.iem.y = __shfl(R.iem.y, src); R.iem.z = __shfl(R.iem.z, src);
+                R.iwp.x = __shfl(R.iwp.x, src); R.iwp.y = __shfl(R.iwp.y, src); R.iwp.z = __shfl(R.iwp.z, src);
+                R.icv.x = __shfl(R.icv.x, src); R.icv.y = __shfl(R.icv.y, src); R.icv.z = __shfl(R.icv.z, src);
+                R.ibrdf = __shfl(R.ibrdf, src);
+            }
+        } else {
+            if (R.leaf) { tr = tr + pr; tg = tg + pg; tb_ = tb_ + pb; }
+        }
+        if (busy) {
+            pstate = nstate;
             if (lvl == 0u) { acc_r = tr; acc_g = tg; acc_b = tb_; }
             else { cu_r = tr; cu_g = tg; cu_b = tb_; }
             if (leader) {
@@ -650,6 +625,7 @@ __global__ __launch_bounds__(RT_BLOCK) void k_render(const RenderParams P, const
                 }
             }
             if (lvl > 0u) kcount += n_valid;
+            if (rounds_left > 0u) rounds_left -= 1u;
 
             if (!last_leaf) {
                 // the last kept sibling is an open hit: it becomes the current level
@@ -659,24 +635,13 @@ __global__ __launch_bounds__(RT_BLOCK) void k_render(const RenderParams P, const
                     stack.st(s, 3, em_r); stack.st(s, 4, em_g); stack.st(s, 5, em_b);
                     stack.st(s, 6, cu_r); stack.st(s, 7, cu_g); stack.st(s, 8, cu_b);
                     stack.st(s, 9, cw.x); stack.st(s, 10, cw.y); stack.st(s, 11, cw.z);
-                    stack.st(s, 12, cn.x); stack.st(s, 13, cn.y); stack.st(s, 14, cn.z);
-                    stack.st(s, 15, cin.x); stack.st(s, 16, cin.y); stack.st(s, 17, cin.z);
-                    stack.st(s, 18, __uint_as_float((kcount << 1) | cur_brdf));
+                    stack.st(s, 12, cv.x); stack.st(s, 13, cv.y); stack.st(s, 14, cv.z);
+                    stack.st(s, 15, __uint_as_float((kcount << 1) | cur_brdf));
                 }
-                if (TT > 1) {
-                    const uint32_t src = team0 + last;
-                    hc_r = __shfl(ihc.x, src); hc_g = __shfl(ihc.y, src); hc_b = __shfl(ihc.z, src);
-                    em_r = __shfl(iem.x, src); em_g = __shfl(iem.y, src); em_b = __shfl(iem.z, src);
-                    cw.x = __shfl(iwp.x, src); cw.y = __shfl(iwp.y, src); cw.z = __shfl(iwp.z, src);
-                    cn.x = __shfl(inr.x, src); cn.y = __shfl(inr.y, src); cn.z = __shfl(inr.z, src);
-                    cin.x = __shfl(idir.x, src); cin.y = __shfl(idir.y, src); cin.z = __shfl(idir.z, src);
-                    cur_brdf = __shfl(ibrdf, src);
-                } else {
-                    hc_r = ihc.x; hc_g = ihc.y; hc_b = ihc.z;
-                    em_r = iem.x; em_g = iem.y; em_b = iem.z;
-                    cw = iwp; cn = inr; cin = idir;
-                    cur_brdf = ibrdf;
-                }
+                hc_r = R.ihc.x; hc_g = R.ihc.y; hc_b = R.ihc.z;
+                em_r = R.iem.x; em_g = R.iem.y; em_b = R.iem.z;
+                cw = R.iwp; cv = R.icv;
+                cur_brdf = R.ibrdf;
                 cu_r = 0.f; cu_g = 0.f; cu_b = 0.f;
                 kcount = 0;
                 lvl += 1u;
@@ -699,98 +664,93 @@ __global__ __launch_bounds__(RT_BLOCK) void k_render(const RenderParams P, const
                     em_r = stack.ld(s, 3); em_g = stack.ld(s, 4); em_b = stack.ld(s, 5);
                     cu_r = stack.ld(s, 6); cu_g = stack.ld(s, 7); cu_b = stack.ld(s, 8);
                     cw.x = stack.ld(s, 9); cw.y = stack.ld(s, 10); cw.z = stack.ld(s, 11);
-                    cn.x = stack.ld(s, 12); cn.y = stack.ld(s, 13); cn.z = stack.ld(s, 14);
-                    cin.x = stack.ld(s, 15); cin.y = stack.ld(s, 16); cin.z = stack.ld(s, 17);
-                    const uint32_t kb = __float_as_uint(stack.ld(s, 18));
+                    cv.x = stack.ld(s, 12); cv.y = stack.ld(s, 13); cv.z = stack.ld(s, 14);
+                    const uint32_t kb = __float_as_uint(stack.ld(s, 15));
                     kcount = kb >> 1;
                     cur_brdf = kb & 1u;
                     cu_r = cu_r + hc_r * wr; cu_g = cu_g + hc_g * wg; cu_b = cu_b + hc_b * wb;   // render.rs:168
                 }
             }
         }
-    }
 
+        RT_DBG_MARK(4);
+        // =====================================================================================
+        // compact out: paths that used up this pass's budget are parked for the next pass
+        // =====================================================================================
+        if (P.budget != 0u) {
+            const bool live = busy || (q != RT_INVALID && samp < aa2);
+            const bool park = live && rounds_left == 0u;
+            const unsigned long long pm = __ballot(park && leader);
+            if (pm != 0ull) {
+                uint32_t base = 0;
+                const uint32_t first = (uint32_t)__builtin_ctzll(pm);
+                if (lane == first) base = atomicAdd(&P.ctl->count[P.pass + 1u], (uint32_t)__popcll(pm));
+                base = __shfl(base, first);
+                uint32_t slot = base + __builtin_amdgcn_mbcnt_hi((uint32_t)(pm >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)pm, 0u));
+                if (TEAMS) slot = __shfl(slot, team0);
+                if (park) {
+                    if (slot < qcap) {
+                        if (leader) {
+                            float* e = q_out + slot;
+                            const uint32_t plvl = busy ? lvl : 0u;
+                            e[0ull * qcap] = __uint_as_float(q);
+                            e[1ull * qcap] = __uint_as_float(samp);
+                            e[2ull * qcap] = __uint_as_float(plvl);
+                            e[3ull * qcap] = __uint_as_float(base_depth);
+                            e[4ull * qcap] = __uint_as_float((uint32_t)mstate); e[5ull * qcap] = __uint_as_float((uint32_t)(mstate >> 32));
+                            e[6ull * qcap] = __uint_as_float((uint32_t)pstate); e[7ull * qcap] = __uint_as_float((uint32_t)(pstate >> 32));
+                            e[8ull * qcap] = __uint_as_float((uint32_t)pinc); e[9ull * qcap] = __uint_as_float((uint32_t)(pinc >> 32));
+                            e[10ull * qcap] = acc_r; e[11ull * qcap] = acc_g; e[12ull * qcap] = acc_b;
+                            if (plvl > 0u) {
+                                float* c = e + (uint64_t)RT_QHEAD * qcap;
+                                c[0ull * qcap] = hc_r; c[1ull * qcap] = hc_g; c[2ull * qcap] = hc_b;
+                                c[3ull * qcap] = em_r; c[4ull * qcap] = em_g; c[5ull * qcap] = em_b;
+                                c[6ull * qcap] = cu_r; c[7ull * qcap] = cu_g; c[8ull * qcap] = cu_b;
+                                c[9ull * qcap] = cw.x; c[10ull * qcap] = cw.y; c[11ull * qcap] = cw.z;
+                                c[12ull * qcap] = cv.x; c[13ull * qcap] = cv.y; c[14ull * qcap] = cv.z;
+                                c[15ull * qcap] = __uint_as_float((kcount << 1) | cur_brdf);
+                                const uint32_t n_saved = (plvl - 1u) * RT_NF;
+                                float* sv = c + (uint64_t)RT_NF * qcap;
+                                for (uint32_t i = 0; i < n_saved; ++i) sv[(uint64_t)i * qcap] = stack.base[i * stack.stride];
+                            }
+                        }
+                        q = RT_INVALID;
+                        busy = false;
+                    } else {
+                        rounds_left = P.budget;   // the queue is full: keep running this path here
+                    }
+                }
+            }
+        }
+        RT_DBG_MARK(5);
+    }
     };   // run_rounds
 
-    if (T2 == 0) {
-        (void)run_rounds(std::integral_constant<int, T>{}, 0u);
-    } else if (run_rounds(std::integral_constant<int, 1>{}, 64u / (uint32_t)(T2 > 0 ? T2 : 1))) {
-        // ---- tail: the queue is empty and at most 64/T2 pixels of this wave are unfinished.  Pack
-        // them into teams of T2 lanes (each lane of a team gets a copy of the pixel's state and of its
-        // LDS stack) and finish them with sibling / survivor speculation: the frame ends when the
-        // longest per-pixel chain of dependent rays ends, and idle lanes are free. ----
-        constexpr uint32_t TT2 = (uint32_t)(T2 > 0 ? T2 : 1);
-        // retire finished pixels still waiting for a refill event
-        if (!busy && q != RT_INVALID && samp == aa2) {
-            float* o = P.out + 3ull * q;
-            o[0] = acc_r * P.inv_samples; o[1] = acc_g * P.inv_samples; o[2] = acc_b * P.inv_samples;
-            q = RT_INVALID;
-            if (dbg_pix_rounds > dbg_max_pix_rounds) dbg_max_pix_rounds = dbg_pix_rounds;
-            dbg_pix_rounds = 0;
-        }
-        const bool live = busy || (q != RT_INVALID);
-        unsigned long long lm = __ballot(live);
-        const uint32_t n_live = (uint32_t)__popcll(lm);
-        const uint32_t tt = lane / TT2;
-        for (uint32_t i = 0; i < tt; ++i) lm &= lm - 1ull;       // drop the tt lowest live lanes
-        const bool has = tt < n_live;
-        const uint32_t src = has ? (uint32_t)__builtin_ctzll(lm) : lane;
-        // counters stay with their lane; everything else moves
-        q = __shfl(q, src); samp = __shfl(samp, src);
-        mstate = __shfl(mstate, src); pstate = __shfl(pstate, src); pinc = __shfl(pinc, src);
-        acc_r = __shfl(acc_r, src); acc_g = __shfl(acc_g, src); acc_b = __shfl(acc_b, src);
-        grow = __shfl(grow, src); gcol = __shfl(gcol, src);
-        busy = __shfl((int)busy, src) != 0;
-        ro.x = __shfl(ro.x, src); ro.y = __shfl(ro.y, src); ro.z = __shfl(ro.z, src);
-        rd.x = __shfl(rd.x, src); rd.y = __shfl(rd.y, src); rd.z = __shfl(rd.z, src);
-        rtmin = __shfl(rtmin, src); rtmax = __shfl(rtmax, src);
-        lvl = __shfl(lvl, src); base_depth = __shfl(base_depth, src);
-        hc_r = __shfl(hc_r, src); hc_g = __shfl(hc_g, src); hc_b = __shfl(hc_b, src);
-        em_r = __shfl(em_r, src); em_g = __shfl(em_g, src); em_b = __shfl(em_b, src);
-        cu_r = __shfl(cu_r, src); cu_g = __shfl(cu_g, src); cu_b = __shfl(cu_b, src);
-        kcount = __shfl(kcount, src); cur_brdf = __shfl(cur_brdf, src);
-        cw.x = __shfl(cw.x, src); cw.y = __shfl(cw.y, src); cw.z = __shfl(cw.z, src);
-        cn.x = __shfl(cn.x, src); cn.y = __shfl(cn.y, src); cn.z = __shfl(cn.z, src);
-        cin.x = __shfl(cin.x, src); cin.y = __shfl(cin.y, src); cin.z = __shfl(cin.z, src);
-        dbg_pix_rounds = __shfl(dbg_pix_rounds, src);
-        if (!has) { q = RT_INVALID; busy = false; }
-        // LDS stack: every (slot, field) is read by all lanes before any lane overwrites it
-        // (LDS operations of one wave execute in order)
-        const float* sbase = lds_stack + (tid - lane + src);
-        for (uint32_t i = 0; i < P.stack_slots * RT_NF; ++i) {
-            const float v = sbase[i * RT_BLOCK];
-            stack.base[i * RT_BLOCK] = v;
-        }
-        exhausted = true;
-        (void)run_rounds(std::integral_constant<int, (T2 > 0 ? T2 : 1)>{}, 0u);
-    }
+    if (T > 1u) run_rounds(std::true_type{});
+    else run_rounds(std::false_type{});
 
     if (P.debug_waves && lane == 0) {
-        unsigned long long* d = P.debug_waves + 5ull * (gtid >> 6);
-        d[0] = dbg_t0; d[1] = __builtin_amdgcn_s_memrealtime(); d[2] = dbg_rounds; d[3] = dbg_lanes;
-    }
-    if (P.debug_waves) {
-        uint32_t mx = dbg_max_pix_rounds;
-#pragma unroll
-        for (int off = 32; off > 0; off >>= 1) { const uint32_t o = __shfl_down(mx, off); mx = o > mx ? o : mx; }
-        if (lane == 0) P.debug_waves[5ull * (gtid >> 6) + 4] = mx;
+        unsigned long long* d = P.debug_waves + 11ull * ((unsigned long long)P.pass * P.debug_stride + (gtid >> 6));
+        d[0] = dbg_t0; d[1] = __builtin_amdgcn_s_memrealtime(); d[2] = dbg_rounds; d[3] = dbg_lanes; d[4] = T;
+        for (int i = 0; i < 6; ++i) d[5 + i] = dbg_sec[i];
     }
     // ---- counters: wave reduction, one atomic per wave and counter ----
-    if (P.counters) {
+    {
         uint32_t c[4] = {n_rays, n_samples, n_diffuse, n_specular};
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             uint32_t v = c[j];
 #pragma unroll
             for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off);
-            if (lane == 0 && v != 0u) atomicAdd(P.counters + j, (unsigned long long)v);
+            if (lane == 0 && v != 0u) atomicAdd(&P.ctl->counters[j], (unsigned long long)v);
         }
     }
 }
 
 // World::ray_intersection for a batch of rays, full HitRecord (src/world.rs:32-50).
 template <bool AFFINE>
-__global__ __launch_bounds__(RT_BLOCK) void k_intersect(const DShape* __restrict__ shapes, uint32_t n_shapes,
+__global__ __launch_bounds__(RT_BLOCK) void k_intersect(const DScan* __restrict__ scan, const DMRows* __restrict__ mrows,
+                                                        const DWRows* __restrict__ wrows, uint32_t n_shapes,
                                                         const rt_ray* __restrict__ rays, uint64_t n, rt_hit* __restrict__ hits) {
     const uint64_t i = (uint64_t)blockIdx.x * RT_BLOCK + threadIdx.x;
     if (i >= n) return;
@@ -798,14 +758,14 @@ __global__ __launch_bounds__(RT_BLOCK) void k_intersect(const DShape* __restrict
     const Vec3 ro = {r.origin[0], r.origin[1], r.origin[2]};
     const Vec3 rd = {r.dir[0], r.dir[1], r.dir[2]};
     float t;
-    const int best = closest_hit<AFFINE>(shapes, n_shapes, ro, rd, r.tmin, r.tmax, t);
+    const int best = scan_closest_hit<AFFINE>(scan, wrows, n_shapes, ro, rd, r.tmin, r.tmax, t);
     rt_hit h;
     h.hit = 0; h.shape = 0; h.t = 0.f;
     h.world_point[0] = h.world_point[1] = h.world_point[2] = 0.f;
     h.normal[0] = h.normal[1] = h.normal[2] = 0.f;
     h.uv[0] = h.uv[1] = 0.f;
     if (best >= 0) {
-        const HitRec rec = hit_record<AFFINE>(shapes + best, ro, rd, t, true);
+        const HitRec rec = scan_hit_record<AFFINE>(scan + best, mrows + best, wrows + best, ro, rd, t, true, true);
         h.hit = 1;
         h.shape = (uint32_t)best;
         h.t = t;
