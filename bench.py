@@ -22,6 +22,7 @@ sys.path.insert(0, ROOT)
 WIDTH, HEIGHT, AA = 1920, 1080, 1
 NUM_OF_RAYS, MAX_DEPTH, RR_LIMIT = 10, 3, 3
 INIT_STATE, INIT_SEQ = 42, 54
+EXPECTED_RAYS = 44180520            # oracle (strict math) ray count of this exact frame; tests/test_gpu_parity.py
 PEAK_FP32_VECTOR_TFLOPS = 157.3     # MI355X_MICROARCH.md: spec, FMA counted as 2 flop
 PEAK_STRICT_NOFMA_TFLOPS = 78.6     # same issue rate with unfused mul/add (reference forbids FMA)
 
@@ -138,6 +139,8 @@ def main():
     st = _abi.rt_stats()
     render(0, C.byref(st))
     my_rays = st.rays
+    if world_size == 1 and my_rays != EXPECTED_RAYS:
+        raise SystemExit(f"ray counter {my_rays} != {EXPECTED_RAYS} (oracle, World::ray_intersection calls of this frame)")
     torch.cuda.synchronize()
 
     for i in range(args.warmup):

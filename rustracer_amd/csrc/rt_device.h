@@ -49,6 +49,16 @@ static_assert(sizeof(DMRows) == 48, "DMRows layout");
 struct __attribute__((aligned(16))) DWRows { float inv_w[4]; float m_w[4]; };
 static_assert(sizeof(DWRows) == 32, "DWRows layout");
 
+// Shading record of a shape (32 B): the colors of its material when both pigments are uniform
+// (material.rs:32-36), so the common case needs two 16-B loads and no pigment evaluation.
+struct __attribute__((aligned(16))) DShade {
+    float hc[3];        // brdf pigment color (uniform)
+    uint32_t flags;     // bit 0: RT_BRDF_*; bit 1 / bit 2: the brdf / emitted pigment reads (u,v) -> evaluate the DMaterial
+    float em[3];        // emitted radiance (uniform)
+    uint32_t pad;
+};
+static_assert(sizeof(DShade) == 32, "DShade layout");
+
 struct DPigment {
     uint32_t kind;      // RT_PIGMENT_*
     float c1[3];
@@ -163,6 +173,28 @@ __device__ __forceinline__ bool sphere_t(Vec3 o, Vec3 d, float tmin, float tmax,
         return true;
     }
     return false;
+}
+
+// The same value and the same decision without control flow: the roots are computed for every lane
+// (sqrt of a negative delta is NaN and fails every comparison; delta <= 0 is rejected explicitly).
+__device__ __forceinline__ bool sphere_t_nb(Vec3 o, Vec3 d, float tmin, float tmax, float& t_out) {
+    const float a = d.x * d.x + d.y * d.y + d.z * d.z;
+    const float b = 2.0f * (o.x * d.x + o.y * d.y + o.z * d.z);
+    const float c = (o.x * o.x + o.y * o.y + o.z * o.z) - 1.0f;
+    const float delta = b * b - 4.0f * a * c;
+    const float sqrt_delta = __builtin_sqrtf(delta);
+    const float a2 = 2.0f * a;
+    const float t1 = (-b - sqrt_delta) / a2;
+    const float t2 = (-b + sqrt_delta) / a2;
+    const bool h1 = (t1 > tmin) && (t1 < tmax);
+    const bool h2 = (t2 > tmin) && (t2 < tmax);
+    t_out = h1 ? t1 : t2;
+    return (delta > 0.0f) && (h1 || h2);
+}
+__device__ __forceinline__ bool plane_t_nb(Vec3 o, Vec3 d, float tmin, float tmax, float& t_out) {
+    const float t = -o.z / d.z;
+    t_out = t;
+    return !(__builtin_fabsf(d.z) < 1e-5f) && !((t <= tmin) || (t >= tmax));
 }
 
 // Plane::ray_intersection up to t (src/shape.rs:196-204).
@@ -306,6 +338,47 @@ __device__ __forceinline__ int scan_closest_hit(const DScan* __restrict__ scan, 
         if (hit && (best < 0 || t < best_t)) {
             best = (int)i;
             best_t = t;
+        }
+    }
+    return best;
+}
+
+// The same scan, G shapes per iteration (loads of a group are issued together) and without
+// control flow inside a shape test; also returns the winner's object-space ray and kind.
+template <bool AFFINE, int G>
+__device__ __forceinline__ int scan_closest_hit_g(const DScan* __restrict__ scan, const DWRows* __restrict__ wrows,
+                                                  uint32_t n_shapes, Vec3 ro, Vec3 rd, float tmin, float tmax,
+                                                  float& best_t, Vec3& best_o, Vec3& best_d, uint32_t& best_kind) {
+    int best = -1;
+    best_t = 0.0f;
+    best_kind = 0u;
+    best_o = {0.f, 0.f, 0.f};
+    best_d = {0.f, 0.f, 0.f};
+    for (uint32_t i0 = 0; i0 < n_shapes; i0 += G) {
+        Rows3 R[G];
+        uint32_t kind[G];
+#pragma unroll
+        for (int g = 0; g < G; ++g) {
+            const uint32_t i = (i0 + g < n_shapes) ? i0 + g : n_shapes - 1u;
+            R[g] = load_rows(scan[i].inv);
+            kind[g] = (uint32_t)__builtin_amdgcn_readfirstlane((int)scan[i].kind);
+        }
+#pragma unroll
+        for (int g = 0; g < G; ++g) {
+            const uint32_t i = (i0 + g < n_shapes) ? i0 + g : n_shapes - 1u;
+            const Vec3 o = rows_point<AFFINE>(R[g], AFFINE ? nullptr : wrows[i].inv_w, ro.x, ro.y, ro.z);
+            const Vec3 d = rows_vector(R[g], rd.x, rd.y, rd.z);
+            float t = 0.0f;
+            bool hit;
+            if (kind[g] == RT_SHAPE_SPHERE) hit = sphere_t_nb(o, d, tmin, tmax, t);
+            else hit = plane_t_nb(o, d, tmin, tmax, t);
+            if ((i0 + g < n_shapes) && hit && (best < 0 || t < best_t)) {
+                best = (int)(i0 + g);
+                best_t = t;
+                best_o = o;
+                best_d = d;
+                best_kind = kind[g];
+            }
         }
     }
     return best;

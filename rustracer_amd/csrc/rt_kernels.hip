@@ -53,8 +53,8 @@ struct TeamTables {
     uint64_t j2_mult[64], j2_geom[64];   // 2j draws
     uint64_t j3_mult[64], j3_geom[64];   // 3j draws
     uint64_t sv_mult[32], sv_geom[32];   // 2 * num_of_rays * s draws
-    uint16_t fwd[64];                    // candidate k -> sibling j | survivors s << 8 (0xFFFF: none)
-    uint8_t inv[256];                    // j*(j+1)/2 + s -> candidate k (255: none)
+    uint16_t fwd[64];                    // team lane k -> sibling j | survivors s << 8 (0xFFFF: none); inverse: tri_index
+    uint8_t pad[256];
 };
 static_assert(sizeof(TeamTables) == 2944, "TeamTables layout");
 
@@ -82,6 +82,8 @@ struct PassParams {
     // partition (row tiles dealt round-robin)
     uint32_t part, n_parts, tile_rows;
     uint32_t n_items;                // pixels of this part / solve items
+    uint32_t n_in0;                  // length of pass 0's (virtual) queue: n_items, or whole 64-pixel granules
+    uint32_t perm_stride;            // 0, or granules per stratum of the pass-0 queue order (see perm_entry)
     // solve mode
     const rt_ray* in_rays;
     rt_pcg* io_pcgs;
@@ -93,6 +95,7 @@ struct PassParams {
     uint32_t lanes_target;           // team size = lanes_target / queue length (power of two, <= max_team)
     uint32_t max_team;
     uint32_t idle_div;               // refill once 1/idle_div of a wave's teams are idle
+    uint32_t backlog;                // queue entries per team slot of the grid (>= 1): fewer, fuller waves
     PassCtl* ctl;
     float* qbuf[2];                  // SoA path-state queues [field][entry]; pass p reads (p-1)&1, writes p&1
     uint32_t q_capacity;
@@ -106,6 +109,16 @@ struct PassParams {
     uint32_t debug_stride;           // waves per pass in debug_waves
 };
 
+// Parameters only the generate / retire / park paths read are fetched from the kernarg segment at
+// the point of use (scalar loads) instead of living in SGPRs for the whole launch: the round loop
+// is long and every resident scalar costs spills.
+typedef const __attribute__((address_space(4))) PassParams* ColdParams;
+__device__ __forceinline__ ColdParams cold_params() {
+    ColdParams p = (ColdParams)__builtin_amdgcn_kernarg_segment_ptr();
+    asm volatile("" : "+s"(p));
+    return p;
+}
+
 // Saved level state accessors: STACK_LDS ? LDS : global.
 template <bool STACK_LDS>
 struct LevelStack {
@@ -117,46 +130,81 @@ struct LevelStack {
 
 // Master PCG of ImageTracer::all_rays at global pixel p: Pcg::new(init_state, init_seq) advanced by
 // p*(2*aa^2+1) draws (imagetracer.rs:63-81), by binary LCG jump-ahead.
-__device__ __forceinline__ uint64_t master_state_at(const PassParams& P, uint32_t p) {
-    uint64_t s = P.master_state0;
+__device__ __forceinline__ uint64_t master_state_at(ColdParams P, uint32_t p) {
+    uint64_t s = P->master_state0;
     for (uint32_t i = 0; p != 0u; ++i, p >>= 1) {
-        const uint64_t s2 = s * P.pix_mult[i] + P.pix_plus[i];
+        const uint64_t s2 = s * P->pix_mult[i] + P->pix_plus[i];
         s = (p & 1u) ? s2 : s;
     }
     return s;
 }
 
+// Master PCG `delta` pixels after state s (per-lane delta, wave-uniform trip count so that the jump
+// table is read with scalar loads).
+__device__ __forceinline__ uint64_t master_jump(ColdParams P, uint64_t s, uint32_t delta) {
+    for (uint32_t i = 0; i < 32u; ++i) {
+        if (__ballot((delta >> i) != 0u) == 0ull) break;
+        const uint64_t s2 = s * P->pix_mult[i] + P->pix_plus[i];
+        s = ((delta >> i) & 1u) ? s2 : s;
+    }
+    return s;
+}
+
+// Pass 0 hands out pixels in a strided order so that every wave sees a mix of cheap (sky) and
+// expensive image regions: queue entry h = (granule g, offset r) with 64-pixel granules; granule g
+// maps to pixel granule (g % 64) * stride + g / 64.  Entries past the last pixel are skipped.
+__device__ __forceinline__ uint32_t perm_entry(uint32_t h, uint32_t stride) {
+    if (stride == 0u) return h;
+    const uint32_t g = h >> 6;
+    return (((g & 63u) * stride + (g >> 6)) << 6) | (h & 63u);
+}
+
 // local pixel -> global (row, col) through the row-tile partition
-__device__ __forceinline__ void local_to_global(const PassParams& P, uint32_t q, uint32_t& grow, uint32_t& gcol) {
-    const uint32_t lrow = q / P.width;
-    gcol = q - lrow * P.width;
-    const uint32_t tile = lrow / P.tile_rows;
-    grow = (tile * P.n_parts + P.part) * P.tile_rows + (lrow - tile * P.tile_rows);
+__device__ __forceinline__ void local_to_global(ColdParams P, uint32_t q, uint32_t& grow, uint32_t& gcol) {
+    const uint32_t width = P->width, tile_rows = P->tile_rows;
+    const uint32_t lrow = q / width;
+    gcol = q - lrow * width;
+    const uint32_t tile = lrow / tile_rows;
+    grow = (tile * P->n_parts + P->part) * tile_rows + (lrow - tile * tile_rows);
 }
 
 // ImageTracer::fire_ray + Camera::fire_ray for sample `samp` of pixel (grow, gcol)
 // (imagetracer.rs:52-56, :67-75; camera.rs:68-75, :132-143); advances the master PCG by two draws.
 template <bool AFFINE>
-__device__ __forceinline__ void primary_ray(const PassParams& P, uint32_t grow, uint32_t gcol, uint32_t samp,
+__device__ __forceinline__ void primary_ray(ColdParams P, uint32_t grow, uint32_t gcol, uint32_t samp,
                                             uint64_t& mstate, Vec3& ro, Vec3& rd) {
-    const uint32_t sub_row = samp / P.aa;
-    const uint32_t sub_col = samp - sub_row * P.aa;
-    const float rf0 = pcg_random_float(mstate, P.master_inc);
-    const float rf1 = pcg_random_float(mstate, P.master_inc);
-    const float u_pixel = ((float)sub_row + rf0) / (float)P.aa;
-    const float v_pixel = ((float)sub_col + rf1) / (float)P.aa;
-    const float u = ((float)gcol + u_pixel) / (float)P.width;
-    const float v = 1.0f - ((float)grow + v_pixel) / (float)P.height;
+    const uint32_t aa = P->aa;
+    const uint64_t minc = P->master_inc;
+    const uint32_t sub_row = samp / aa;
+    const uint32_t sub_col = samp - sub_row * aa;
+    const float rf0 = pcg_random_float(mstate, minc);
+    const float rf1 = pcg_random_float(mstate, minc);
+    const float u_pixel = ((float)sub_row + rf0) / (float)aa;
+    const float v_pixel = ((float)sub_col + rf1) / (float)aa;
+    const float u = ((float)gcol + u_pixel) / (float)P->width;
+    const float v = 1.0f - ((float)grow + v_pixel) / (float)P->height;
+    const float dist = P->cam_distance, aspect = P->cam_aspect;
     float cox, coy, coz, cdx, cdy, cdz;
-    if (P.cam_kind == RT_CAMERA_ORTHOGONAL) {
-        cox = -1.0f; coy = (1.0f - 2.0f * u) * P.cam_aspect; coz = 2.0f * v - 1.0f;
+    if (P->cam_kind == RT_CAMERA_ORTHOGONAL) {
+        cox = -1.0f; coy = (1.0f - 2.0f * u) * aspect; coz = 2.0f * v - 1.0f;
         cdx = 1.0f; cdy = 0.0f; cdz = 0.0f;
     } else {
-        cox = -P.cam_distance; coy = 0.0f; coz = 0.0f;
-        cdx = P.cam_distance; cdy = (1.0f - 2.0f * u) * P.cam_aspect; cdz = 2.0f * v - 1.0f;
+        cox = -dist; coy = 0.0f; coz = 0.0f;
+        cdx = dist; cdy = (1.0f - 2.0f * u) * aspect; cdz = 2.0f * v - 1.0f;
     }
-    ro = xform_point<AFFINE>(P.cam_m, cox, coy, coz);
-    rd = xform_vector(P.cam_m, cdx, cdy, cdz);
+    float M[16];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) M[i] = P->cam_m[i];
+    ro = xform_point<AFFINE>(M, cox, coy, coz);
+    rd = xform_vector(M, cdx, cdy, cdz);
+}
+
+// Lane (within its team) of last-level candidate (sibling j, s earlier survivors): rows of the
+// triangle in order, inside a row the most probable survivor counts first (|2s - j| ascending).
+__device__ __forceinline__ uint32_t tri_index(uint32_t j, uint32_t s) {
+    const int dlt = 2 * (int)s - (int)j;
+    const uint32_t rank = (dlt < 0) ? (uint32_t)(-dlt - 1) : (uint32_t)dlt;
+    return ((j * (j + 1u)) >> 1) + rank;
 }
 
 __device__ __forceinline__ uint64_t shfl_u64(uint64_t v, uint32_t src) {
@@ -190,10 +238,17 @@ struct NodeOut {
 // true, folds their radiances IN SIBLING ORDER, adopts the PCG state of the last sibling kept and
 // re-speculates the rest.  Every draw and every f32 operation equals the sequential recursion of
 // PathTracer::solve (src/render.rs:136-172); only the latency changes.
-template <bool AFFINE, bool STACK_LDS, bool SCENE_LDS>
-__global__ __launch_bounds__(RT_BLOCK) void k_pass(const PassParams P, const DScan* __restrict__ g_scan,
+#ifndef RT_WAVES_PER_EU
+#define RT_WAVES_PER_EU 3
+#endif
+#ifndef RT_SCAN_GROUP
+#define RT_SCAN_GROUP 2
+#endif
+template <bool AFFINE, bool STACK_LDS, bool SCENE_LDS, bool TEAMS>
+__global__ __launch_bounds__(RT_BLOCK, RT_WAVES_PER_EU) void k_pass(const PassParams P, const DScan* __restrict__ g_scan,
                                                    const DMRows* __restrict__ g_mrows,
                                                    const DWRows* __restrict__ g_wrows,
+                                                   const DShade* __restrict__ g_shade,
                                                    const DMaterial* __restrict__ g_materials,
                                                    const float* __restrict__ texels) {
     extern __shared__ float4 lds_raw[];
@@ -202,33 +257,35 @@ __global__ __launch_bounds__(RT_BLOCK) void k_pass(const PassParams P, const DSc
     const uint32_t gtid = blockIdx.x * RT_BLOCK + tid;
 
     // ---- this pass's input and team size (wave-uniform, the same in every wave) ----
-    uint32_t n_in = P.n_items;
+    ColdParams C0 = cold_params();
+    uint32_t n_in = C0->n_in0;
     if (P.pass != 0u) {
         n_in = P.ctl->count[P.pass];
-        if (n_in > P.q_capacity) n_in = P.q_capacity;
+        if (n_in > C0->q_capacity) n_in = C0->q_capacity;
     }
     n_in = (uint32_t)__builtin_amdgcn_readfirstlane((int)n_in);
     if (n_in == 0u) return;
     uint32_t T = 1u;
-    if (P.max_team > 1u) {
-        uint32_t r = P.lanes_target / n_in;
-        if (r > P.max_team) r = P.max_team;
+    if (C0->max_team > 1u) {
+        uint32_t r = C0->lanes_target / n_in;
+        if (r > C0->max_team) r = C0->max_team;
         while (T * 2u <= r) T *= 2u;
     }
-    if ((uint64_t)blockIdx.x * (RT_BLOCK / T) >= (uint64_t)n_in) return;   // more blocks than work
-    const float* __restrict__ q_in = P.qbuf[(P.pass + 1u) & 1u];
-    float* __restrict__ q_out = P.qbuf[P.pass & 1u];
-    const uint32_t qcap = P.q_capacity;
+    // the team variant of the kernel also runs T == 1 (later passes, whose queue length only the
+    // device knows); the single variant is launched for passes the host pins to one lane per pixel
+    if (!TEAMS) T = 1u;
+    if ((uint64_t)blockIdx.x * (RT_BLOCK / T) * C0->backlog >= (uint64_t)n_in && blockIdx.x != 0u) return;   // more blocks than work
 
-    // ---- LDS: [team tables][DScan x n][DMRows x n][DMaterial x n (one per shape)][recursion stack] ----
+    // ---- LDS: [team tables][DScan x n][DMRows x n][DShade x n][DMaterial x n (one per shape)][recursion stack] ----
     TeamTables* lds_tab = reinterpret_cast<TeamTables*>(lds_raw);
     const uint32_t n_staged = SCENE_LDS ? P.n_shapes : 0u;
-    DScan* lds_scan = reinterpret_cast<DScan*>(reinterpret_cast<unsigned char*>(lds_raw) + sizeof(TeamTables));
+    DScan* lds_scan = reinterpret_cast<DScan*>(reinterpret_cast<unsigned char*>(lds_raw) + (TEAMS ? sizeof(TeamTables) : 0));
     DMRows* lds_mrows = reinterpret_cast<DMRows*>(lds_scan + n_staged);
-    DMaterial* lds_mats = reinterpret_cast<DMaterial*>(lds_mrows + n_staged);
+    DShade* lds_shade = reinterpret_cast<DShade*>(lds_mrows + n_staged);
+    DMaterial* lds_mats = reinterpret_cast<DMaterial*>(lds_shade + n_staged);
     float* lds_stack = reinterpret_cast<float*>(lds_mats + n_staged);
-    if (T > 1u) {
-        const uint32_t* src = reinterpret_cast<const uint32_t*>(P.tables);
+    if (TEAMS) {
+        const uint32_t* src = reinterpret_cast<const uint32_t*>(C0->tables);
         uint32_t* dst = reinterpret_cast<uint32_t*>(lds_tab);
         for (uint32_t i = tid; i < (uint32_t)(sizeof(TeamTables) / 4); i += RT_BLOCK) dst[i] = src[i];
     }
@@ -243,6 +300,9 @@ __global__ __launch_bounds__(RT_BLOCK) void k_pass(const PassParams P, const DSc
         uint32_t* dst_r = reinterpret_cast<uint32_t*>(lds_mrows);
         const uint32_t* src_r = reinterpret_cast<const uint32_t*>(g_mrows);
         for (uint32_t i = tid; i < n_staged * (uint32_t)(sizeof(DMRows) / 4); i += RT_BLOCK) dst_r[i] = src_r[i];
+        uint32_t* dst_h = reinterpret_cast<uint32_t*>(lds_shade);
+        const uint32_t* src_h = reinterpret_cast<const uint32_t*>(g_shade);
+        for (uint32_t i = tid; i < n_staged * (uint32_t)(sizeof(DShade) / 4); i += RT_BLOCK) dst_h[i] = src_h[i];
         uint32_t* dst_m = reinterpret_cast<uint32_t*>(lds_mats);
         constexpr uint32_t MW = sizeof(DMaterial) / 4;
         for (uint32_t i = tid; i < n_staged * MW; i += RT_BLOCK) {
@@ -250,16 +310,17 @@ __global__ __launch_bounds__(RT_BLOCK) void k_pass(const PassParams P, const DSc
             dst_m[i] = reinterpret_cast<const uint32_t*>(g_materials + g_scan[sh].material)[j];
         }
     }
-    if (T > 1u || SCENE_LDS) __syncthreads();
+    if (TEAMS || SCENE_LDS) __syncthreads();
     const DScan* __restrict__ scan = SCENE_LDS ? lds_scan : g_scan;
     const DMRows* __restrict__ mrows = SCENE_LDS ? lds_mrows : g_mrows;
+    const DShade* __restrict__ shade = SCENE_LDS ? lds_shade : g_shade;
     const DMaterial* __restrict__ mats = SCENE_LDS ? lds_mats : g_materials;
 
     LevelStack<STACK_LDS> stack;
     if (STACK_LDS) { stack.base = lds_stack + tid; stack.stride = RT_BLOCK; }
-    else { stack.base = P.gstack + gtid; stack.stride = P.total_threads; }
+    else { stack.base = C0->gstack + gtid; stack.stride = C0->total_threads; }
 
-    const uint32_t aa2 = P.aa * P.aa;
+    const uint32_t aa2 = C0->aa * C0->aa;
     const uint32_t n_children = P.num_of_rays;
     const uint32_t n_qfields = RT_QHEAD + RT_NF * (1u + P.stack_slots);
     (void)n_qfields;
@@ -270,10 +331,7 @@ __global__ __launch_bounds__(RT_BLOCK) void k_pass(const PassParams P, const DSc
     uint64_t mstate = 0;            // master PCG state at the next jitter draw of q
     uint64_t pstate = 0, pinc = 1;  // the pixel's PCG (state before this round's draws)
     float acc_r = 0.f, acc_g = 0.f, acc_b = 0.f;
-    uint32_t grow = 0, gcol = 0;    // global row / column of q
     bool busy = false;              // a top-level solve of q is in flight
-    Vec3 ro = {0.f, 0.f, 0.f}, rd = {1.f, 0.f, 0.f};   // the level-0 ray of that solve
-    float rtmin = 1e-5f, rtmax = __builtin_inff();
     uint32_t lvl = 0;               // recursion level of the rays traced next (0 = the level-0 ray)
     uint32_t base_depth = 0;        // Ray.depth of the level-0 ray
     uint32_t rounds_left = 0;       // of this pass's budget
@@ -288,15 +346,17 @@ __global__ __launch_bounds__(RT_BLOCK) void k_pass(const PassParams P, const DSc
 
     // wave-private slice of the input queue
     uint32_t wcur = 0, wend = 0;
+    uint32_t wbase_q = 0, wbase_h = 0, wbase_p = 0;   // pass 0: first pixel of the wave's current chunk,
+    uint64_t wbase_state = 0;                        // its queue entry, global index and master PCG state
     bool exhausted = false;
     // diagnostics
     unsigned long long dbg_t0 = 0;
     uint32_t dbg_rounds = 0, dbg_lanes = 0;
     if (P.debug_waves) dbg_t0 = __builtin_amdgcn_s_memrealtime();
     // section cycle counters (diagnostics): 0 generate 1 scatter 2 scan 3 hit+shade 4 resolve 5 park
-    uint32_t dbg_sec[6] = {0, 0, 0, 0, 0, 0};
+    uint32_t dbg_sec0 = 0, dbg_sec1 = 0, dbg_sec2 = 0, dbg_sec3 = 0, dbg_sec4 = 0, dbg_sec5 = 0;
     uint64_t dbg_prev = 0;
-#define RT_DBG_MARK(i) do { if (P.debug_waves) { const uint64_t now_ = __builtin_readcyclecounter(); dbg_sec[i] += (uint32_t)(now_ - dbg_prev); dbg_prev = now_; } } while (0)
+#define RT_DBG_MARK(i) do { if (P.debug_waves) { const uint64_t now_ = __builtin_readcyclecounter(); dbg_sec##i += (uint32_t)(now_ - dbg_prev); dbg_prev = now_; } } while (0)
 
     // ---------------------------------------------------------------------------------------------
     // one node: intersect + shade (render.rs:57-67, :76-89, :136-171)
@@ -311,7 +371,9 @@ __global__ __launch_bounds__(RT_BLOCK) void k_pass(const PassParams P, const DSc
         }
         if (P.algorithm == RT_ALGO_PATHTRACER && depth > P.max_depth) return;   // render.rs:137-139
         float t;
-        const int best = scan_closest_hit<AFFINE>(scan, g_wrows, P.n_shapes, o, d, tmin, tmax, t);
+        Vec3 lo, ld;                 // the winner's object-space ray
+        uint32_t bkind;
+        const int best = scan_closest_hit_g<AFFINE, RT_SCAN_GROUP>(scan, g_wrows, P.n_shapes, o, d, tmin, tmax, t, lo, ld, bkind);
         R.traced = true;
         RT_DBG_MARK(2);
         if (best < 0) {
@@ -322,12 +384,30 @@ __global__ __launch_bounds__(RT_BLOCK) void k_pass(const PassParams P, const DSc
             R.vr = P.fg[0]; R.vg = P.fg[1]; R.vb = P.fg[2];   // render.rs:61-66
             return;
         }
-        const DScan* S = scan + best;
-        const DMaterial* M = mats + S->material;
+        // HitRecord of the winner (src/shape.rs:134-142, :205-213): only the fields that are read
+        const float4* shp = reinterpret_cast<const float4*>(shade + best);
+        const float4 sh0 = shp[0], sh1 = shp[1];
+        Vec3 hc = {sh0.x, sh0.y, sh0.z};
+        Vec3 em = {sh1.x, sh1.y, sh1.z};
+        const uint32_t sflags = __float_as_uint(sh0.w);
         const bool can_open = (P.algorithm == RT_ALGO_PATHTRACER) && (depth + 1u <= P.max_depth);
-        const HitRec h = scan_hit_record<AFFINE>(S, mrows + best, g_wrows + best, o, d, t, S->needs_uv != 0u, can_open);
-        Vec3 hc = pigment_color(&M->brdf_pigment, texels, h.u, h.v);
-        const Vec3 em = pigment_color(&M->emitted, texels, h.u, h.v);
+        const float hx = lo.x + ld.x * t, hy = lo.y + ld.y * t, hz = lo.z + ld.z * t;   // inv_ray.at(t)
+        const bool sphere = (bkind == RT_SHAPE_SPHERE);
+        if (sflags & 6u) {
+            // some pigment of this material reads (u, v)
+            float u, v;
+            if (sphere) {
+                u = rt_atan2f(hy, hx) / 6.2831854820251465f;  // 2.0 * PI in f32
+                v = rt_acosf(hz) / 3.1415927410125732f;       // PI in f32
+                if (u < 0.0f) u += 1.0f;
+            } else {
+                u = hx - __builtin_floorf(hx);
+                v = hy - __builtin_floorf(hy);
+            }
+            const DMaterial* M = mats + (SCENE_LDS ? (uint32_t)best : scan[best].material);
+            if (sflags & 2u) hc = pigment_color(&M->brdf_pigment, texels, u, v);
+            if (sflags & 4u) em = pigment_color(&M->emitted, texels, u, v);
+        }
         if (P.algorithm == RT_ALGO_FLAT) {
             R.vr = em.x + hc.x; R.vg = em.y + hc.y; R.vb = em.z + hc.z;   // render.rs:83-84
             return;
@@ -357,12 +437,26 @@ __global__ __launch_bounds__(RT_BLOCK) void k_pass(const PassParams P, const DSc
                 R.vb = em.z + cb * P.inv_num_of_rays;
             } else {
                 R.leaf = false;
-                R.ihc = hc; R.iem = em; R.iwp = h.world_point;
-                R.ibrdf = M->brdf;
+                R.ihc = hc; R.iem = em;
+                R.ibrdf = sflags & 1u;
+                // world_point and normal of the hit (src/shape.rs:88-95, :134-138, :175-182, :205-209)
+                const Rows3 MW = load_rows(mrows[best].m);
+                const Rows3 IW = load_rows(scan[best].inv);
+                R.iwp = rows_point<AFFINE>(MW, AFFINE ? nullptr : g_wrows[best].m_w, hx, hy, hz);
+                float nx, ny, nz, dp;
+                if (sphere) {
+                    dp = hx * ld.x + hy * ld.y + hz * ld.z;
+                    nx = hx; ny = hy; nz = hz;
+                } else {
+                    dp = 0.0f * ld.x + 0.0f * ld.y + 1.0f * ld.z;
+                    nx = 0.0f; ny = 0.0f; nz = 1.0f;
+                }
+                if (!(dp < 0.0f)) { nx = -nx; ny = -ny; nz = -nz; }
+                const Vec3 nrm = rows_normal(IW, nx, ny, nz);
                 // SpecularBRDF::scatter_ray ignores its draws: every child of this hit has the same
                 // direction, computed once from hit.ray.dir and hit.normal (material.rs:225-246)
-                if (R.ibrdf == RT_BRDF_SPECULAR) R.icv = specular_scatter_dir(d, h.normal);
-                else R.icv = h.normal;
+                if (R.ibrdf == RT_BRDF_SPECULAR) R.icv = specular_scatter_dir(d, nrm);
+                else R.icv = nrm;
             }
         } else {
             // no children: emitted + 0 * (1/n) (render.rs:157, :171)
@@ -375,15 +469,14 @@ __global__ __launch_bounds__(RT_BLOCK) void k_pass(const PassParams P, const DSc
     // ---------------------------------------------------------------------------------------------
     // the round loop
     // ---------------------------------------------------------------------------------------------
-    auto run_rounds = [&](auto teams_tag) {
-    constexpr bool TEAMS = decltype(teams_tag)::value;
+    {
     const uint32_t TT = TEAMS ? T : 1u;
     const uint32_t jj = TEAMS ? (lane & (TT - 1u)) : 0u;       // candidate slot of this lane
     const uint32_t team0 = TEAMS ? (lane & ~(TT - 1u)) : lane; // first lane of the team
     const bool leader = (jj == 0u);
     const unsigned long long tmask = (TT >= 64u) ? ~0ull : ((1ull << TT) - 1ull);
     const uint32_t n_teams = 64u / TT;
-    uint32_t idle_min = n_teams / P.idle_div;
+    uint32_t idle_min = n_teams / cold_params()->idle_div;
     if (idle_min < 1u) idle_min = 1u;
 
     if (P.debug_waves) dbg_prev = __builtin_readcyclecounter();
@@ -396,18 +489,20 @@ __global__ __launch_bounds__(RT_BLOCK) void k_pass(const PassParams P, const DSc
         const unsigned long long busy_any = __ballot(busy);
         if (idle_leaders != 0ull && ((uint32_t)__popcll(idle_leaders) >= idle_min || busy_any == 0ull)) {
             bool want = false;
+            ColdParams C = cold_params();
             if (!busy) {
                 if (q != RT_INVALID && samp == aa2) {
                     // pixel (or solve item) finished: color * (1 / aa^2)  (imagetracer.rs:121)
                     if (leader) {
-                        float* o = P.out + 3ull * q;
+                        float* o = C->out + 3ull * q;
                         if (P.mode == 0u) {
-                            o[0] = acc_r * P.inv_samples;
-                            o[1] = acc_g * P.inv_samples;
-                            o[2] = acc_b * P.inv_samples;
+                            const float inv_samples = C->inv_samples;
+                            o[0] = acc_r * inv_samples;
+                            o[1] = acc_g * inv_samples;
+                            o[2] = acc_b * inv_samples;
                         } else {
                             o[0] = acc_r; o[1] = acc_g; o[2] = acc_b;
-                            P.io_pcgs[q].state = pstate;
+                            C->io_pcgs[q].state = pstate;
                         }
                     }
                     q = RT_INVALID;
@@ -418,6 +513,8 @@ __global__ __launch_bounds__(RT_BLOCK) void k_pass(const PassParams P, const DSc
             bool lead_want = want && leader;
             unsigned long long wantmask = __ballot(lead_want);
             uint32_t h = RT_INVALID;
+            uint32_t my_base_p = 0;          // the chunk base this lane's entry was taken from
+            uint64_t my_base_state = 0;
             while (wantmask != 0ull) {
                 if (wcur == wend) {
                     uint32_t b = 0;
@@ -426,6 +523,17 @@ __global__ __launch_bounds__(RT_BLOCK) void k_pass(const PassParams P, const DSc
                     if (b >= n_in) { exhausted = true; break; }
                     wcur = b;
                     wend = (b + n_teams < n_in) ? b + n_teams : n_in;
+                    if (P.pass == 0u && P.mode == 0u) {
+                        // master PCG at the chunk's first pixel, on the scalar unit (imagetracer.rs:63-81)
+                        wbase_h = b;
+                        wbase_q = (uint32_t)__builtin_amdgcn_readfirstlane((int)perm_entry(b, C->perm_stride));
+                        if (wbase_q < P.n_items) {
+                            uint32_t r0, c0;
+                            local_to_global(C, wbase_q, r0, c0);
+                            wbase_p = (uint32_t)__builtin_amdgcn_readfirstlane((int)(r0 * C->width + c0));
+                            wbase_state = master_state_at(C, wbase_p);
+                        }
+                    }
                 }
                 const uint32_t avail = wend - wcur;
                 const uint32_t wanted = (uint32_t)__popcll(wantmask);
@@ -433,12 +541,24 @@ __global__ __launch_bounds__(RT_BLOCK) void k_pass(const PassParams P, const DSc
                 const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(wantmask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)wantmask, 0u));
                 if (lead_want && rank < cnt) {
                     h = wcur + rank;
+                    // pass 0: the chunk's entries are consecutive pixels starting at wbase_q
+                    if (P.pass == 0u && P.mode == 0u) {
+                        h = wbase_q + (h - wbase_h);
+                        my_base_p = wbase_p;
+                        my_base_state = wbase_state;
+                        if (h >= P.n_items) h = RT_INVALID - 1u;   // ragged end of the strided order: nothing to do
+                    }
                     lead_want = false;
                 }
                 wcur += cnt;
                 wantmask = __ballot(lead_want);
             }
-            if (TEAMS) h = __shfl(h, team0);
+            if (TEAMS) {
+                h = __shfl(h, team0);
+                my_base_p = __shfl(my_base_p, team0);
+                my_base_state = shfl_u64(my_base_state, team0);
+            }
+            if (h == RT_INVALID - 1u) h = RT_INVALID;
             if (!busy && h != RT_INVALID) {
                 rounds_left = P.budget;
                 if (P.pass == 0u) {
@@ -447,18 +567,20 @@ __global__ __launch_bounds__(RT_BLOCK) void k_pass(const PassParams P, const DSc
                     acc_r = 0.f; acc_g = 0.f; acc_b = 0.f;
                     lvl = 0;
                     if (P.mode == 0u) {
-                        local_to_global(P, q, grow, gcol);
+                        uint32_t grow, gcol;
+                        local_to_global(C, q, grow, gcol);
                         // master PCG at this pixel: jump ahead p*(2*aa^2+1) draws (imagetracer.rs:63-81)
-                        const uint64_t s = master_state_at(P, grow * P.width + gcol);
+                        const uint64_t s = master_jump(C, my_base_state, grow * C->width + gcol - my_base_p);
                         mstate = s;
                         // seq = the u32 drawn after the pixel's 2*aa^2 jitter draws (imagetracer.rs:79)
-                        const uint64_t sq = s * P.seq_mult + P.seq_plus;
+                        const uint64_t sq = s * C->seq_mult + C->seq_plus;
                         const uint64_t seq = (uint64_t)pcg_output(sq);
-                        pcg_new(P.init_state, seq, pstate, pinc);   // imagetracer.rs:117
+                        pcg_new(C->init_state, seq, pstate, pinc);   // imagetracer.rs:117
                     }
                 } else {
                     // a path parked by the previous pass
-                    const float* e = q_in + h;
+                    const uint32_t qcap = C->q_capacity;
+                    const float* e = C->qbuf[(P.pass + 1u) & 1u] + h;
                     q = __float_as_uint(e[0ull * qcap]);
                     samp = __float_as_uint(e[1ull * qcap]);
                     lvl = __float_as_uint(e[2ull * qcap]);
@@ -467,7 +589,6 @@ __global__ __launch_bounds__(RT_BLOCK) void k_pass(const PassParams P, const DSc
                     pstate = (uint64_t)__float_as_uint(e[6ull * qcap]) | ((uint64_t)__float_as_uint(e[7ull * qcap]) << 32);
                     pinc = (uint64_t)__float_as_uint(e[8ull * qcap]) | ((uint64_t)__float_as_uint(e[9ull * qcap]) << 32);
                     acc_r = e[10ull * qcap]; acc_g = e[11ull * qcap]; acc_b = e[12ull * qcap];
-                    if (P.mode == 0u) local_to_global(P, q, grow, gcol);
                     if (lvl > 0u) {
                         const float* c = e + (uint64_t)RT_QHEAD * qcap;
                         hc_r = c[0ull * qcap]; hc_g = c[1ull * qcap]; hc_b = c[2ull * qcap];
@@ -486,21 +607,14 @@ __global__ __launch_bounds__(RT_BLOCK) void k_pass(const PassParams P, const DSc
                 }
             }
             if (!busy && q != RT_INVALID) {
-                // start the next top-level solve of q (imagetracer.rs:118-120)
+                // start the next top-level solve of q (imagetracer.rs:118-120); its level-0 ray is
+                // produced in the candidate stage below
                 if (P.mode == 0u) {
-                    primary_ray<AFFINE>(P, grow, gcol, samp, mstate, ro, rd);
-                    rtmin = 1e-5f;
-                    rtmax = __builtin_inff();
                     base_depth = 0;
                 } else {
-                    const rt_ray r = P.in_rays[q];
-                    ro = {r.origin[0], r.origin[1], r.origin[2]};
-                    rd = {r.dir[0], r.dir[1], r.dir[2]};
-                    rtmin = r.tmin;
-                    rtmax = r.tmax;
-                    base_depth = r.depth;
-                    pstate = P.io_pcgs[q].state;
-                    pinc = P.io_pcgs[q].inc;
+                    base_depth = C->in_rays[q].depth;
+                    pstate = C->io_pcgs[q].state;
+                    pinc = C->io_pcgs[q].inc;
                 }
                 samp += 1;
                 if (leader) n_samples += 1;
@@ -508,7 +622,10 @@ __global__ __launch_bounds__(RT_BLOCK) void k_pass(const PassParams P, const DSc
                 busy = true;
             }
         }
-        if (__ballot(busy) == 0ull) break;  // queue empty and every team retired or parked
+        if (__ballot(busy) == 0ull) {
+            if (exhausted) break;           // queue empty and every team retired or parked
+            continue;                       // only skipped entries so far: take more
+        }
         RT_DBG_MARK(0);
 
         // =====================================================================================
@@ -519,14 +636,16 @@ __global__ __launch_bounds__(RT_BLOCK) void k_pass(const PassParams P, const DSc
         const uint32_t pred = (lvl > 0u && depth >= P.rr_limit) ? 1u : 0u;
         const bool last_level = TEAMS && (lvl > 0u) && (depth == P.max_depth);
         uint32_t cj = jj, cs = 0u;   // this lane's candidate: sibling kcount+cj, cs earlier survivors
+        bool cand_ok = true;
         if (TEAMS && last_level) {
             const uint32_t fw = lds_tab->fwd[jj];
             cj = fw & 0xFFu;
-            cs = fw >> 8;
+            cs = (fw >> 8) & 31u;
+            cand_ok = (fw != 0xFFFFu);
         }
         uint32_t n_rem = 0;          // rays this level still has to start
         if (busy) n_rem = (lvl == 0u) ? 1u : (n_children - kcount);
-        const bool act = busy && ((lvl == 0u) ? (jj == 0u) : (cj < n_rem));
+        const bool act = busy && ((lvl == 0u) ? (jj == 0u) : (cand_ok && cj < n_rem));
         if (P.debug_waves) { dbg_rounds += 1u; dbg_lanes += (uint32_t)__popcll(__ballot(act)); }
 
         uint64_t st = pstate;        // this lane's PCG, advanced through its own ray's draws
@@ -535,12 +654,25 @@ __global__ __launch_bounds__(RT_BLOCK) void k_pass(const PassParams P, const DSc
         R.vr = 0.f; R.vg = 0.f; R.vb = 0.f;
         R.ihc = {0.f, 0.f, 0.f}; R.iem = {0.f, 0.f, 0.f}; R.iwp = {0.f, 0.f, 0.f}; R.icv = {0.f, 0.f, 1.f};
         R.ibrdf = 0u;
-        if (act) {
-            Vec3 o, d;
-            float tmin, tmax;
-            if (lvl == 0u) {
-                o = ro; d = rd; tmin = rtmin; tmax = rtmax;
+        Vec3 o = {0.f, 0.f, 0.f}, d = {1.f, 0.f, 0.f};
+        float tmin = 1e-5f, tmax = __builtin_inff();
+        if (busy && lvl == 0u) {
+            // the level-0 ray of sample samp-1 (every lane of the team: the master PCG stays replicated)
+            ColdParams C = cold_params();
+            if (P.mode == 0u) {
+                uint32_t grow, gcol;
+                local_to_global(C, q, grow, gcol);
+                primary_ray<AFFINE>(C, grow, gcol, samp - 1u, mstate, o, d);
             } else {
+                const rt_ray r = C->in_rays[q];
+                o = {r.origin[0], r.origin[1], r.origin[2]};
+                d = {r.dir[0], r.dir[1], r.dir[2]};
+                tmin = r.tmin;
+                tmax = r.tmax;
+            }
+        }
+        if (act) {
+            if (lvl != 0u) {
                 // BRDF::scatter_ray of this lane's sibling (render.rs:160-166)
                 if (TEAMS) {
                     if (pred) st = st * lds_tab->j3_mult[cj] + pinc * lds_tab->j3_geom[cj];
@@ -580,25 +712,33 @@ __global__ __launch_bounds__(RT_BLOCK) void k_pass(const PassParams P, const DSc
             const unsigned long long b_traced = (__ballot(R.traced) >> team0) & tmask;
             const unsigned long long b_lo = (__ballot(act && R.leaf && (lvl == 0u || R.consumed == pred)) >> team0) & tmask;
             const unsigned long long b_hi = (__ballot(act && R.leaf && last_level && R.consumed == pred + 2u * n_children) >> team0) & tmask;
-            uint32_t surv = 0u, j = 0u;
+            // phase 1: which candidates lie on the true path (bit operations only).  hi_hist bit j:
+            // sibling j of this round survived the roulette; the lane of candidate (j, s) is
+            // tri_index(j, s) at the last level and j elsewhere.
+            uint32_t surv = 0u, j = 0u, hi_hist = 0u;
             bool cont = busy;            // sibling j of this round is on the true path
             n_valid = 0u; traced_valid = 0u;
             while (__ballot(cont) != 0ull) {
-                uint32_t idx = j;
-                if (last_level) idx = (j < RT_TRI_J) ? (uint32_t)lds_tab->inv[((j * (j + 1u)) >> 1) + surv] : 255u;
+                const uint32_t idx = last_level ? tri_index(j, surv) : j;
                 const bool ok = cont && idx < TT && ((b_act >> idx) & 1ull) != 0ull;
-                const uint32_t src = team0 + (ok ? idx : 0u);
-                const float qr = __shfl(pr, src), qg = __shfl(pg, src), qb = __shfl(pb, src);
                 if (ok) {
                     n_valid = j + 1u;
                     last = idx;
                     traced_valid += (uint32_t)((b_traced >> idx) & 1ull);
-                    if ((b_leaf >> idx) & 1ull) { tr = tr + qr; tg = tg + qg; tb_ = tb_ + qb; }
                 }
                 const bool hi = ok && ((b_hi >> idx) & 1ull) != 0ull;
-                cont = ok && (hi || ((b_lo >> idx) & 1ull) != 0ull);
-                if (hi) surv += 1u;
+                cont = ok && (hi || ((b_lo >> idx) & 1ull) != 0ull) && j < 31u;
+                if (hi) { surv += 1u; hi_hist |= 1u << j; }
                 j += 1u;
+            }
+            // phase 2: fold the kept leaves into the level, in sibling order (render.rs:168 / imagetracer.rs:119)
+            for (j = 0u; __ballot(busy && j < n_valid) != 0ull; ++j) {
+                const uint32_t sj = (uint32_t)__popc(hi_hist & ((1u << j) - 1u));
+                const uint32_t idx = last_level ? tri_index(j, sj) : j;
+                const bool ok = busy && j < n_valid;
+                const uint32_t src = team0 + (ok ? idx : 0u);
+                const float qr = __shfl(pr, src), qg = __shfl(pg, src), qb = __shfl(pb, src);
+                if (ok && ((b_leaf >> idx) & 1ull) != 0ull) { tr = tr + qr; tg = tg + qg; tb_ = tb_ + qb; }
             }
             last_leaf = ((b_leaf >> last) & 1ull) != 0ull;
             nstate = shfl_u64(st, team0 + last);
@@ -682,6 +822,9 @@ __global__ __launch_bounds__(RT_BLOCK) void k_pass(const PassParams P, const DSc
             const bool park = live && rounds_left == 0u;
             const unsigned long long pm = __ballot(park && leader);
             if (pm != 0ull) {
+                ColdParams C = cold_params();
+                const uint32_t qcap = C->q_capacity;
+                float* q_out = C->qbuf[P.pass & 1u];
                 uint32_t base = 0;
                 const uint32_t first = (uint32_t)__builtin_ctzll(pm);
                 if (lane == first) base = atomicAdd(&P.ctl->count[P.pass + 1u], (uint32_t)__popcll(pm));
@@ -724,26 +867,21 @@ __global__ __launch_bounds__(RT_BLOCK) void k_pass(const PassParams P, const DSc
         }
         RT_DBG_MARK(5);
     }
-    };   // run_rounds
-
-    if (T > 1u) run_rounds(std::true_type{});
-    else run_rounds(std::false_type{});
+    }   // round loop
 
     if (P.debug_waves && lane == 0) {
         unsigned long long* d = P.debug_waves + 11ull * ((unsigned long long)P.pass * P.debug_stride + (gtid >> 6));
         d[0] = dbg_t0; d[1] = __builtin_amdgcn_s_memrealtime(); d[2] = dbg_rounds; d[3] = dbg_lanes; d[4] = T;
-        for (int i = 0; i < 6; ++i) d[5 + i] = dbg_sec[i];
+        d[5] = dbg_sec0; d[6] = dbg_sec1; d[7] = dbg_sec2; d[8] = dbg_sec3; d[9] = dbg_sec4; d[10] = dbg_sec5;
     }
     // ---- counters: wave reduction, one atomic per wave and counter ----
     {
-        uint32_t c[4] = {n_rays, n_samples, n_diffuse, n_specular};
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            uint32_t v = c[j];
+        auto flush = [&](uint32_t v, int j) {
 #pragma unroll
             for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off);
             if (lane == 0 && v != 0u) atomicAdd(&P.ctl->counters[j], (unsigned long long)v);
-        }
+        };
+        flush(n_rays, 0); flush(n_samples, 1); flush(n_diffuse, 2); flush(n_specular, 3);
     }
 }
 

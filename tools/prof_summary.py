@@ -10,7 +10,7 @@ for d in ("pmc1", "pmc2", "pmc3", "pmc4"):
     for f in glob.glob(f"{root}/{d}/*/*_counter_collection.csv"):
         agg = collections.defaultdict(lambda: collections.defaultdict(list))
         for r in csv.DictReader(open(f)):
-            k = "k_render" if "k_render" in r["Kernel_Name"] else "k_classify" if "k_classify" in r["Kernel_Name"] else None
+            k = "k_pass" if "k_pass" in r["Kernel_Name"] else None
             if k:
                 agg[k][r["Counter_Name"]].append(float(r["Counter_Value"]))
                 meta = {x: r[x] for x in ("Grid_Size", "Workgroup_Size", "LDS_Block_Size", "VGPR_Count", "SGPR_Count", "Scratch_Size")}
@@ -19,6 +19,6 @@ for d in ("pmc1", "pmc2", "pmc3", "pmc4"):
             for name, v in cs.items():
                 if name == "_meta":
                     continue
-                print(f"{k:11s} {name:26s} {sum(v)/len(v):.5g}")
+                print(f"{k:11s} {name:26s} mean/dispatch {sum(v)/len(v):.5g}  dispatches {len(v)}")
             if d == "pmc1":
                 print(f"{k:11s} launch {cs['_meta']}")
