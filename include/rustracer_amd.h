@@ -140,6 +140,15 @@ rt_scene* rt_scene_create(const rt_shape* shapes, uint32_t n_shapes,
                           const rt_texture* textures, uint32_t n_textures);
 void rt_scene_destroy(rt_scene* scene);
 
+/* Scheduling of rt_render on this scene (never changes a pixel; no counterpart in the reference,
+ * where rayon schedules pixels, src/imagetracer.rs:112-123).  A path-traced frame is a sequence of
+ * passes: a pixel runs at most budgets[p] rays deep into its recursion in pass p, then its path state
+ * is parked in HBM and picked up, compacted into full wavefronts, by pass p+1; the pass after the
+ * last budget has no limit.  n_budgets == 0 restores the default (short passes: lowest latency of
+ * one frame); budgets = {0} renders every pixel in one pass (best throughput when several frames
+ * are in flight on different streams). */
+int rt_scene_set_schedule(rt_scene* scene, const uint32_t* budgets, uint32_t n_budgets);
+
 /* Number of pixels of `part` (rows * width), i.e. the length/3 of the buffer rt_render fills. */
 uint64_t rt_partition_pixels(uint32_t width, uint32_t height, const rt_partition* part);
 

@@ -239,7 +239,7 @@ struct NodeOut {
 // re-speculates the rest.  Every draw and every f32 operation equals the sequential recursion of
 // PathTracer::solve (src/render.rs:136-172); only the latency changes.
 #ifndef RT_WAVES_PER_EU
-#define RT_WAVES_PER_EU 3
+#define RT_WAVES_PER_EU 4
 #endif
 #ifndef RT_SCAN_GROUP
 #define RT_SCAN_GROUP 2
@@ -356,7 +356,11 @@ __global__ __launch_bounds__(RT_BLOCK, RT_WAVES_PER_EU) void k_pass(const PassPa
     // section cycle counters (diagnostics): 0 generate 1 scatter 2 scan 3 hit+shade 4 resolve 5 park
     uint32_t dbg_sec0 = 0, dbg_sec1 = 0, dbg_sec2 = 0, dbg_sec3 = 0, dbg_sec4 = 0, dbg_sec5 = 0;
     uint64_t dbg_prev = 0;
+#ifdef RT_DEBUG_SECTIONS   // per-section cycle counters cost ~10 VGPRs: diagnostics builds only (make EXTRA=-DRT_DEBUG_SECTIONS)
 #define RT_DBG_MARK(i) do { if (P.debug_waves) { const uint64_t now_ = __builtin_readcyclecounter(); dbg_sec##i += (uint32_t)(now_ - dbg_prev); dbg_prev = now_; } } while (0)
+#else
+#define RT_DBG_MARK(i) do { (void)dbg_prev; } while (0)
+#endif
 
     // ---------------------------------------------------------------------------------------------
     // one node: intersect + shade (render.rs:57-67, :76-89, :136-171)

@@ -6,9 +6,14 @@ demo_world / demo_camera restate the constants of the reference's `demo` subcomm
 import numpy as np
 
 from .camera import OrthogonalCamera, PerspectiveCamera
-from .material import (BLACK, CheckeredPigment, DiffuseBRDF, Material, SpecularBRDF, UniformPigment)
+import math
+
+from .hdrimage import HdrImage
+from .material import (BLACK, WHITE, CheckeredPigment, DiffuseBRDF, ImagePigment, Material, SpecularBRDF,
+                       UniformPigment)
+from .random import Pcg
 from .shape import Plane, Sphere
-from .transformation import Transformation, rotation_z, scaling, to_radians, translation
+from .transformation import Transformation, rotation_y, rotation_z, scaling, to_radians, translation
 from .world import World
 
 F = np.float32
@@ -35,3 +40,125 @@ def demo_camera(width, height, angle_deg=0.0, orthogonal=False):
     if orthogonal:
         return OrthogonalCamera(aspect, tr)
     return PerspectiveCamera(1.0, aspect, tr)
+
+
+# ---------------------------------------------------------------------------------------------
+# C4: sphere-flake (examples/flake.cue restated; `cue` is not available here)
+# ---------------------------------------------------------------------------------------------
+def _compose(entries):
+    """`compose:` list of the scene format: later entries multiply on the LEFT (src/scene.rs:969, :993)."""
+    t = Transformation()
+    for kind, arg in entries:
+        if kind == "scaling":
+            e = scaling(arg)
+        elif kind == "translation":
+            e = translation(arg)
+        elif kind == "rotationy":
+            e = rotation_y(to_radians(arg))       # f32::to_radians (src/scene.rs:890)
+        elif kind == "rotationz":
+            e = rotation_z(to_radians(arg))       # src/scene.rs:895
+        else:
+            raise ValueError(kind)
+        t = e * t
+    return t
+
+
+def _flake_compose_lists(levels=2):
+    """The `_flakes` comprehension of examples/flake.cue:44-89, in its order (duplicates included).
+    Numbers are evaluated in binary64 like cue's float arithmetic and become f32 when parsed."""
+    out = []
+
+    def head(i):
+        sc = 1.0 / math.pow(3, i)
+        return [("scaling", (sc, sc, sc)), ("translation", (1.0 / math.pow(3, i - 1) + 1.0 / math.pow(3, i), 0.0, 0.0))]
+
+    def lifts(i):
+        r = []
+        for l in range(1, i):
+            d = 1.0 / math.pow(3, l - 1) + 1.0 / math.pow(3, l)
+            r.append(("translation", (d * math.sin(math.pi * 0.5 * l), 0.0, d * math.cos(math.pi * 0.5 * l))))
+        return r
+
+    for i in range(1, levels + 1):            # lower spheres cross lower spheres (flake.cue:46-55)
+        for j in range(int(math.pow(6, i - 1))):
+            for k in range(6):
+                out.append(head(i) + [("rotationz", 60 * k), ("rotationy", 90 * (i - 1))] + lifts(i) + [("rotationz", 60 * j)])
+    for i in range(1, levels + 1):            # upper spheres cross lower spheres (flake.cue:57-66)
+        for j in range(int(math.pow(6, i - 1))):
+            for k in range(3):
+                out.append(head(i) + [("rotationy", -45), ("rotationz", 120 * k + 30), ("rotationy", 90 * (i - 1))] + lifts(i)
+                           + [("rotationz", 60 * j)])
+    for i in range(1, levels + 1):            # lower spheres cross upper spheres (flake.cue:68-77)
+        for j in range(int(math.pow(6, i - 1)) * 3 * (i - 1)):
+            for k in range(6):
+                out.append(head(i) + [("rotationz", 60 * k), ("rotationy", 90 * (i - 1))] + lifts(i)
+                           + [("rotationy", -45), ("rotationz", 120 * j + 30)])
+    for i in range(1, levels + 1):            # upper spheres cross upper spheres (flake.cue:79-88)
+        for j in range(int(math.pow(6, i - 1)) * 3 * (i - 1)):
+            for k in range(3):
+                out.append(head(i) + [("rotationy", -45), ("rotationz", 120 * k + 30), ("rotationy", 90 * (i - 1))] + lifts(i)
+                           + [("rotationy", -45), ("rotationz", 120 * j + 30)])
+    return out
+
+
+def procedural_texture(width=64, height=32, seed=7):
+    """A small HDR texture drawn from the host PCG (stands in for a PFM file; fixed seed)."""
+    pcg = Pcg(seed, 1)
+    img = HdrImage(width, height)
+    px = np.empty((height, width, 3), dtype=np.float32)
+    for r in range(height):
+        for c in range(width):
+            px[r, c] = [F(0.2) + F(0.8) * pcg.random_float() for _ in range(3)]
+    img.set_pixels(px)
+    return img
+
+
+def flake_world(textured=False):
+    """examples/flake.cue: 228 shapes (sky sphere, ground plane, centre sphere + 225 mirror spheres).
+    textured=True is BASELINE config 4's variant: checkered ground, image-pigment sky emission."""
+    c = lambda r, g, b: (float(F(r / 255.0)), float(F(g / 255.0)), float(F(b / 255.0)))
+    sky_emit = ImagePigment(procedural_texture()) if textured else UniformPigment(WHITE)
+    ground_pig = CheckeredPigment(c(255, 142, 80), c(80, 142, 255), 8) if textured else UniformPigment(c(255, 142, 80))
+    sky = Material(DiffuseBRDF(UniformPigment(c(0, 221, 255))), sky_emit)
+    flake = Material(SpecularBRDF(UniformPigment(c(95, 95, 95))), UniformPigment(BLACK))
+    ground = Material(DiffuseBRDF(ground_pig), UniformPigment(BLACK))
+    world = World()
+    world.add(Sphere(_compose([("scaling", (100, 100, 100)), ("translation", (0, 0, 0.5))]), sky))
+    world.add(Plane(_compose([("translation", (0, 0, -1))]), ground))
+    world.add(Sphere(Transformation(), flake))
+    for entries in _flake_compose_lists():
+        world.add(Sphere(_compose(entries), flake))
+    return world
+
+
+def flake_camera(width, height, angle_deg=0.0):
+    """flake.cue:24-35 + the extra rotation_z(angle) the `render` subcommand applies (src/scene.rs:1202)."""
+    tr = rotation_z(to_radians(angle_deg)) * _compose([("translation", (-2, 0, 0)), ("rotationy", 48)])
+    return PerspectiveCamera(1.0, float(F(F(width) / F(height))), tr)
+
+
+# ---------------------------------------------------------------------------------------------
+# C5: synthetic N random spheres + ground plane + emissive sky (SURVEY.md section 8d)
+# ---------------------------------------------------------------------------------------------
+def random_spheres_world(n_spheres=10000, seed=2024, seq=1, extent=50.0):
+    """n spheres resting on the ground, centres uniform in [-extent, extent]^2, radii U(0.2, 0.6),
+    80 % diffuse / 20 % specular, colours U(0.1, 0.9)^3, all drawn from the host PCG; plus one
+    emissive sky sphere and one checkered ground plane (n + 2 shapes)."""
+    pcg = Pcg(seed, seq)
+    u = lambda lo, hi: float(F(lo) + F(hi - lo) * pcg.random_float())
+    world = World()
+    sky = Material(DiffuseBRDF(UniformPigment(BLACK)), UniformPigment((1.0, 0.9, 0.5)))
+    ground = Material(DiffuseBRDF(CheckeredPigment((0.3, 0.5, 0.1), (0.1, 0.2, 0.5), 10)), UniformPigment(BLACK))
+    world.add(Sphere(scaling((4.0 * extent, 4.0 * extent, 4.0 * extent)), sky))
+    world.add(Plane(Transformation(), ground))
+    for _ in range(n_spheres):
+        x, y, r = u(-extent, extent), u(-extent, extent), u(0.2, 0.6)
+        col = (u(0.1, 0.9), u(0.1, 0.9), u(0.1, 0.9))
+        brdf = SpecularBRDF(UniformPigment(col)) if pcg.random_float() < F(0.2) else DiffuseBRDF(UniformPigment(col))
+        world.add(Sphere(translation((x, y, r)) * scaling((r, r, r)), Material(brdf, UniformPigment(BLACK))))
+    return world
+
+
+def random_spheres_camera(width, height):
+    tr = translation((-12.0, 0.0, 3.0)) * rotation_y(to_radians(12.0))
+    return PerspectiveCamera(1.0, float(F(F(width) / F(height))), tr)

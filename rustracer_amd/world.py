@@ -116,6 +116,11 @@ class DeviceScene:
         if not self.handle:
             raise _abi.RtError(_abi.lib().rt_last_error().decode())
 
+    def set_schedule(self, budgets=()):
+        """rt_scene_set_schedule: () = default passes, (0,) = one pass, else per-pass ray budgets."""
+        arr = (C.c_uint32 * max(1, len(budgets)))(*budgets)
+        _abi.check(_abi.lib().rt_scene_set_schedule(self.handle, arr, len(budgets)))
+
     def close(self):
         if self.handle:
             _abi.lib().rt_scene_destroy(self.handle)

@@ -311,3 +311,135 @@ def test_errors_are_reported_not_swallowed():
     bad.shapes[0].material = 99
     assert not lib.rt_scene_create(*bad.args())
     assert b"material index" in lib.rt_last_error()
+
+
+# ---- pass schedules, team sizes, large scenes (the wavefront machinery must never change a pixel) ----
+def gpu_render(world, cam, renderer, w, h, init_state=42, init_seq=54, aa=1, schedule=(), stream=None, out=None):
+    """rt_render with the scene resident in HBM (the path bench.py times)."""
+    import torch
+    dev = world.device()
+    dev.set_schedule(schedule)
+    c, r = flatten_camera(cam), renderer.flatten()
+    if out is None:
+        out = torch.empty((h, w, 3), dtype=torch.float32, device="cuda")
+    st = _abi.rt_stats()
+    s = (stream or torch.cuda.current_stream()).cuda_stream
+    _abi.check(_abi.lib().rt_render(dev.handle, C.byref(c), C.byref(r), w, h, init_state, init_seq, aa, None,
+                                    out.data_ptr(), s, C.byref(st) if stream is None else None))
+    dev.set_schedule(())
+    return out, st.as_dict()
+
+
+COUNTERS = ("rays", "samples", "sphere_tests", "plane_tests", "diffuse_scatters", "specular_scatters")
+
+
+@pytest.mark.parametrize("size", [(24, 16), (200, 112), (512, 288)])
+def test_pass_schedules_and_team_sizes_never_change_a_pixel(size, monkeypatch):
+    w, h = size
+    world = demo_world()
+    cam, rr = demo_camera(w, h), ra.PathTracer(world, ra.BLACK, 10, 3, 3)
+    ref, rs = oracle_image(world, cam, rr, w, h)
+    for schedule in [(), (0,), (1,), (3, 5, 7), (40,), (200, 400)]:
+        for max_team in (None, "1", "2", "8"):
+            if max_team is None:
+                monkeypatch.delenv("RUSTRACER_MAX_TEAM", raising=False)
+            else:
+                monkeypatch.setenv("RUSTRACER_MAX_TEAM", max_team)
+            g, gs = gpu_render(world, cam, rr, w, h, schedule=schedule)
+            assert_bit_equal(g.cpu().numpy(), ref, f"{size} schedule={schedule} max_team={max_team}")
+            for k in COUNTERS:
+                assert gs[k] == rs[k], (size, schedule, max_team, k, gs[k], rs[k])
+
+
+def test_antialiased_pixels_parked_between_samples():
+    world = demo_world()
+    w, h = 64, 36
+    cam, rr = demo_camera(w, h), ra.PathTracer(world, ra.BLACK, 3, 2, 1)
+    ref, rs = oracle_image(world, cam, rr, w, h, aa=3)
+    for schedule in [(), (1,), (2, 3), (0,)]:
+        g, gs = gpu_render(world, cam, rr, w, h, aa=3, schedule=schedule)
+        assert_bit_equal(g.cpu().numpy(), ref, f"aa=3 schedule={schedule}")
+        assert gs["rays"] == rs["rays"] and gs["samples"] == rs["samples"]
+
+
+def test_solve_batch_with_short_passes():
+    rng = np.random.default_rng(5)
+    world = demo_world()
+    flat = flatten_world(world)
+    rays = _rays(rng, 300)
+    pcgs = [(int(rng.integers(0, 2**63)), int(rng.integers(0, 2**62)) * 2 + 1) for _ in rays]
+    r = ra.PathTracer(world, (0.1, 0.2, 0.3), 6, 3, 2).flatten()
+    ref, new = O.renderer_solve(flat, r, rays, pcgs)
+    for schedule in [(2,), (5, 9)]:
+        world.device().set_schedule(schedule)
+        arr = (_abi.rt_ray * len(rays))(*rays)
+        pa = (_abi.rt_pcg * len(rays))(*[_abi.rt_pcg(s, i) for s, i in pcgs])
+        out = np.zeros((len(rays), 3), dtype=np.float32)
+        _abi.check(_abi.lib().rt_renderer_solve(world.device().handle, C.byref(r), arr, pa, len(rays), O.fptr(out)))
+        world.device().set_schedule(())
+        assert_bit_equal(out, ref, f"solve schedule={schedule}")
+        assert [(pa[i].state, pa[i].inc) for i in range(len(rays))] == new
+
+
+def test_c3_headline_frame_1920x1080_bit_exact():
+    """The whole frame bench.py times (BASELINE config 3): every f32 of every pixel and every counter."""
+    w, h = 1920, 1080
+    world = demo_world()
+    cam, rr = demo_camera(w, h), ra.PathTracer(world, ra.BLACK, 10, 3, 3)
+    ref, rs = oracle_image(world, cam, rr, w, h)
+    assert rs["rays"] == 44180520
+    for schedule in [(), (0,)]:
+        g, gs = gpu_render(world, cam, rr, w, h, schedule=schedule)
+        assert_bit_equal(g.cpu().numpy(), ref, f"headline frame schedule={schedule}")
+        for k in COUNTERS:
+            assert gs[k] == rs[k], (schedule, k)
+
+
+def test_frames_in_flight_on_separate_streams():
+    import torch
+    w, h = 320, 180
+    world = demo_world()
+    cam, rr = demo_camera(w, h), ra.PathTracer(world, ra.BLACK, 10, 3, 3)
+    ref, _ = oracle_image(world, cam, rr, w, h)
+    streams = [torch.cuda.Stream() for _ in range(3)]
+    outs = [torch.zeros((h, w, 3), dtype=torch.float32, device="cuda") for _ in range(9)]
+    for i, o in enumerate(outs):       # 9 frames over 3 streams: every work slot is reused
+        gpu_render(world, cam, rr, w, h, schedule=(0,) if i % 2 else (), stream=streams[i % 3], out=o)
+    torch.cuda.synchronize()
+    for i, o in enumerate(outs):
+        assert_bit_equal(o.cpu().numpy(), ref, f"frame {i} in flight")
+
+
+def test_c4_flake_228_shapes_scene_in_hbm():
+    """BASELINE config 4 at an oracle-sized resolution: 228 shapes (scan table read from HBM with
+    scalar loads, not LDS), mirror spheres; plain and with checkered + image pigments."""
+    from rustracer_amd.scenes import flake_camera, flake_world
+    w, h = 96, 54
+    for textured in (False, True):
+        world = flake_world(textured)
+        assert len(world.shapes) == 228
+        cam = flake_camera(w, h)
+        check_image(world, cam, ra.FlatRenderer(world, ra.BLACK), w, h, aa=2)
+        rr = ra.PathTracer(world, ra.BLACK, 4, 3, 2)
+        ref, rs = oracle_image(world, cam, rr, w, h)
+        for schedule in [(), (0,), (6, 11)]:
+            g, gs = gpu_render(world, cam, rr, w, h, schedule=schedule)
+            assert_bit_equal(g.cpu().numpy(), ref, f"flake textured={textured} schedule={schedule}")
+            for k in COUNTERS:
+                assert gs[k] == rs[k], (textured, schedule, k)
+
+
+def test_c5_random_spheres_10002_shapes():
+    """BASELINE config 5's scene at an oracle-sized resolution."""
+    from rustracer_amd.scenes import random_spheres_camera, random_spheres_world
+    world = random_spheres_world(10000)
+    assert len(world.shapes) == 10002
+    w, h = 64, 36
+    cam = random_spheres_camera(w, h)
+    check_image(world, cam, ra.OnOffRenderer(world, ra.BLACK, ra.WHITE), w, h)
+    rr = ra.PathTracer(world, ra.BLACK, 3, 2, 2)
+    ref, rs = oracle_image(world, cam, rr, w, h)
+    g, gs = gpu_render(world, cam, rr, w, h)
+    assert_bit_equal(g.cpu().numpy(), ref, "random spheres")
+    for k in COUNTERS:
+        assert gs[k] == rs[k], k
