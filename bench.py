@@ -61,6 +61,9 @@ def main():
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--tile-rows", type=int, default=1)
     ap.add_argument("--inflight", type=int, default=3, help="frames in flight on separate HIP streams (1..4)")
+    ap.add_argument("--schedule", choices=["auto", "passes", "onepass"], default="auto",
+                    help="rt_scene_set_schedule: 'passes' = short passes (lowest single-frame latency), 'onepass' = one "
+                         "pass per frame (best throughput with frames in flight); auto = onepass iff --inflight > 1")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
@@ -87,6 +90,8 @@ def main():
     cam = flatten_camera(demo_camera(WIDTH, HEIGHT))
     rr = ra.PathTracer(scene, ra.BLACK, NUM_OF_RAYS, MAX_DEPTH, RR_LIMIT).flatten()
     dev = scene.device()          # World resident in HBM before the timed region
+    onepass = args.schedule == "onepass" or (args.schedule == "auto" and args.inflight > 1)
+    dev.set_schedule((0,) if onepass else ())
     stream = torch.cuda.current_stream()
 
     part = _abi.rt_partition(rank, world_size, args.tile_rows)
@@ -187,7 +192,8 @@ def main():
             "roofline": {"bound": "valu", "achieved": achieved, "peak": PEAK_FP32_VECTOR_TFLOPS, "unit": "TFLOP/s",
                          "frac": achieved / PEAK_FP32_VECTOR_TFLOPS, "traffic": None,
                          "kernel": "k_render (+k_classify)", "kernel_ms": kernel_ms, "launch_latency_ms": latency_ms,
-                         "frames_in_flight": F, "rays_per_launch": my_rays,
+                         "frames_in_flight": F, "schedule": "onepass" if onepass else "passes",
+                         "rays_per_launch": my_rays,
                          "flops_per_ray": fpr, "peak_strict_nofma": PEAK_STRICT_NOFMA_TFLOPS,
                          "frac_strict_nofma": achieved / PEAK_STRICT_NOFMA_TFLOPS},
         }

@@ -161,6 +161,19 @@ int rt_render(const rt_scene* scene, const rt_camera* camera, const rt_renderer*
               uint32_t antialiasing_level, const rt_partition* part /* NULL = whole image */,
               float* d_out_rgb, void* stream, rt_stats* stats /* nullable */);
 
+/* rt_render for n_frames frames of the same World in ONE launch (an animation: the reference renders
+ * its 360-frame demo.gif by calling `demo --angle-deg a` once per frame, makefile:13-15,
+ * src/main.rs:197): frame f uses cameras[f] and fills d_out_rgb[f] (DEVICE buffers; the array of
+ * pointers itself is host memory).  Every frame is ImageTracer::fire_all_rays with the same seeds,
+ * renderer and partition; pixels of all frames share one queue, which keeps the GPU full where a
+ * single frame leaves most lanes waiting on a few deep pixels.  rt_render == n_frames 1.
+ * `stats` counts all frames of the launch. */
+int rt_render_frames(const rt_scene* scene, const rt_camera* cameras, uint32_t n_frames,
+                     const rt_renderer* renderer, uint32_t width, uint32_t height,
+                     uint64_t init_state, uint64_t init_seq, uint32_t antialiasing_level,
+                     const rt_partition* part /* NULL = whole image */,
+                     float* const* d_out_rgb, void* stream, rt_stats* stats /* nullable */);
+
 /* Inverse of the row-tile partition: scatter `n_parts` gathered part buffers (each padded to
  * `part_stride_pixels` pixels, DEVICE memory) into the full image d_image_rgb (DEVICE). */
 int rt_unpack_parts(const float* d_parts_rgb, uint64_t part_stride_pixels, uint32_t n_parts,

@@ -86,6 +86,9 @@ SIGNATURES = {
     "rt_render": (C.c_int, [C.c_void_p, P(rt_camera), P(rt_renderer), C.c_uint32, C.c_uint32,
                             C.c_uint64, C.c_uint64, C.c_uint32, P(rt_partition), C.c_void_p,
                             C.c_void_p, P(rt_stats)]),
+    "rt_render_frames": (C.c_int, [C.c_void_p, P(rt_camera), C.c_uint32, P(rt_renderer), C.c_uint32, C.c_uint32,
+                                   C.c_uint64, C.c_uint64, C.c_uint32, P(rt_partition), P(C.c_void_p),
+                                   C.c_void_p, P(rt_stats)]),
     "rt_unpack_parts": (C.c_int, [C.c_void_p, C.c_uint64, C.c_uint32, C.c_uint32, C.c_uint32,
                                   C.c_uint32, C.c_void_p, C.c_void_p]),
     "rt_fire_all_rays": (C.c_int, [P(rt_shape), C.c_uint32, P(rt_material), C.c_uint32,

@@ -58,14 +58,24 @@ struct TeamTables {
 };
 static_assert(sizeof(TeamTables) == 2944, "TeamTables layout");
 
+// One frame of a multi-frame launch (rt_render_frames): its camera and its output buffer.
+struct FrameEntry {
+    float cam_m[16];                 // Camera transformation.m (src/camera.rs)
+    uint32_t cam_kind;
+    float cam_distance, cam_aspect;
+    uint32_t pad;
+    float* out;
+    uint64_t pad2;
+};
+static_assert(sizeof(FrameEntry) == 96, "FrameEntry layout");
+
 // Everything a pass needs, passed by value (kernarg -> SGPRs).
 struct PassParams {
     uint32_t n_shapes;
     uint32_t mode;                   // 0: image render; 1: batch Renderer::solve on caller (ray, pcg)
-    // camera (src/camera.rs)
-    uint32_t cam_kind;
-    float cam_distance, cam_aspect;
-    float cam_m[16];
+    // frames of this launch (mode 0): item id = frame * n_per_frame + local pixel
+    const FrameEntry* frames;
+    uint32_t n_frames, n_per_frame;
     // renderer (src/render.rs)
     uint32_t algorithm;
     float bg[3], fg[3];
@@ -81,13 +91,13 @@ struct PassParams {
     uint64_t seq_mult, seq_plus;          // master jump by 2*aa^2 draws (to the pixel's seq draw)
     // partition (row tiles dealt round-robin)
     uint32_t part, n_parts, tile_rows;
-    uint32_t n_items;                // pixels of this part / solve items
+    uint32_t n_items;                // n_frames * (pixels of this part) / solve items
     uint32_t n_in0;                  // length of pass 0's (virtual) queue: n_items, or whole 64-pixel granules
     uint32_t perm_stride;            // 0, or granules per stratum of the pass-0 queue order (see perm_entry)
     // solve mode
     const rt_ray* in_rays;
     rt_pcg* io_pcgs;
-    // outputs
+    // outputs (mode 1; mode 0 writes FrameEntry.out)
     float* out;
     // pass control
     uint32_t pass;                   // 0: fresh items; p > 0: path states parked by pass p-1
@@ -160,10 +170,13 @@ __device__ __forceinline__ uint32_t perm_entry(uint32_t h, uint32_t stride) {
 }
 
 // local pixel -> global (row, col) through the row-tile partition
-__device__ __forceinline__ void local_to_global(ColdParams P, uint32_t q, uint32_t& grow, uint32_t& gcol) {
-    const uint32_t width = P->width, tile_rows = P->tile_rows;
-    const uint32_t lrow = q / width;
-    gcol = q - lrow * width;
+__device__ __forceinline__ void local_to_global(ColdParams P, uint32_t item, uint32_t& frame, uint32_t& lq,
+                                                uint32_t& grow, uint32_t& gcol) {
+    const uint32_t width = P->width, tile_rows = P->tile_rows, npf = P->n_per_frame;
+    frame = (P->n_frames > 1u) ? item / npf : 0u;
+    lq = item - frame * npf;
+    const uint32_t lrow = lq / width;
+    gcol = lq - lrow * width;
     const uint32_t tile = lrow / tile_rows;
     grow = (tile * P->n_parts + P->part) * tile_rows + (lrow - tile * tile_rows);
 }
@@ -171,8 +184,8 @@ __device__ __forceinline__ void local_to_global(ColdParams P, uint32_t q, uint32
 // ImageTracer::fire_ray + Camera::fire_ray for sample `samp` of pixel (grow, gcol)
 // (imagetracer.rs:52-56, :67-75; camera.rs:68-75, :132-143); advances the master PCG by two draws.
 template <bool AFFINE>
-__device__ __forceinline__ void primary_ray(ColdParams P, uint32_t grow, uint32_t gcol, uint32_t samp,
-                                            uint64_t& mstate, Vec3& ro, Vec3& rd) {
+__device__ __forceinline__ void primary_ray(ColdParams P, const FrameEntry* __restrict__ F, uint32_t grow, uint32_t gcol,
+                                            uint32_t samp, uint64_t& mstate, Vec3& ro, Vec3& rd) {
     const uint32_t aa = P->aa;
     const uint64_t minc = P->master_inc;
     const uint32_t sub_row = samp / aa;
@@ -183,9 +196,9 @@ __device__ __forceinline__ void primary_ray(ColdParams P, uint32_t grow, uint32_
     const float v_pixel = ((float)sub_col + rf1) / (float)aa;
     const float u = ((float)gcol + u_pixel) / (float)P->width;
     const float v = 1.0f - ((float)grow + v_pixel) / (float)P->height;
-    const float dist = P->cam_distance, aspect = P->cam_aspect;
+    const float dist = F->cam_distance, aspect = F->cam_aspect;
     float cox, coy, coz, cdx, cdy, cdz;
-    if (P->cam_kind == RT_CAMERA_ORTHOGONAL) {
+    if (F->cam_kind == RT_CAMERA_ORTHOGONAL) {
         cox = -1.0f; coy = (1.0f - 2.0f * u) * aspect; coz = 2.0f * v - 1.0f;
         cdx = 1.0f; cdy = 0.0f; cdz = 0.0f;
     } else {
@@ -194,7 +207,7 @@ __device__ __forceinline__ void primary_ray(ColdParams P, uint32_t grow, uint32_
     }
     float M[16];
 #pragma unroll
-    for (int i = 0; i < 16; ++i) M[i] = P->cam_m[i];
+    for (int i = 0; i < 16; ++i) M[i] = F->cam_m[i];
     ro = xform_point<AFFINE>(M, cox, coy, coz);
     rd = xform_vector(M, cdx, cdy, cdz);
 }
@@ -346,7 +359,7 @@ __global__ __launch_bounds__(RT_BLOCK, RT_WAVES_PER_EU) void k_pass(const PassPa
 
     // wave-private slice of the input queue
     uint32_t wcur = 0, wend = 0;
-    uint32_t wbase_q = 0, wbase_h = 0, wbase_p = 0;   // pass 0: first pixel of the wave's current chunk,
+    uint32_t wbase_q = 0, wbase_h = 0, wbase_p = 0, wbase_f = 0;   // pass 0: first pixel of the wave's current chunk,
     uint64_t wbase_state = 0;                        // its queue entry, global index and master PCG state
     bool exhausted = false;
     // diagnostics
@@ -498,13 +511,16 @@ __global__ __launch_bounds__(RT_BLOCK, RT_WAVES_PER_EU) void k_pass(const PassPa
                 if (q != RT_INVALID && samp == aa2) {
                     // pixel (or solve item) finished: color * (1 / aa^2)  (imagetracer.rs:121)
                     if (leader) {
-                        float* o = C->out + 3ull * q;
                         if (P.mode == 0u) {
+                            uint32_t fr, lq, gr_, gc_;
+                            local_to_global(C, q, fr, lq, gr_, gc_);
+                            float* o = C->frames[fr].out + 3ull * lq;
                             const float inv_samples = C->inv_samples;
                             o[0] = acc_r * inv_samples;
                             o[1] = acc_g * inv_samples;
                             o[2] = acc_b * inv_samples;
                         } else {
+                            float* o = C->out + 3ull * q;
                             o[0] = acc_r; o[1] = acc_g; o[2] = acc_b;
                             C->io_pcgs[q].state = pstate;
                         }
@@ -517,7 +533,7 @@ __global__ __launch_bounds__(RT_BLOCK, RT_WAVES_PER_EU) void k_pass(const PassPa
             bool lead_want = want && leader;
             unsigned long long wantmask = __ballot(lead_want);
             uint32_t h = RT_INVALID;
-            uint32_t my_base_p = 0;          // the chunk base this lane's entry was taken from
+            uint32_t my_base_p = 0, my_base_f = 0;   // the chunk base this lane's entry was taken from
             uint64_t my_base_state = 0;
             while (wantmask != 0ull) {
                 if (wcur == wend) {
@@ -532,8 +548,9 @@ __global__ __launch_bounds__(RT_BLOCK, RT_WAVES_PER_EU) void k_pass(const PassPa
                         wbase_h = b;
                         wbase_q = (uint32_t)__builtin_amdgcn_readfirstlane((int)perm_entry(b, C->perm_stride));
                         if (wbase_q < P.n_items) {
-                            uint32_t r0, c0;
-                            local_to_global(C, wbase_q, r0, c0);
+                            uint32_t f0, lq0, r0, c0;
+                            local_to_global(C, wbase_q, f0, lq0, r0, c0);
+                            wbase_f = (uint32_t)__builtin_amdgcn_readfirstlane((int)f0);
                             wbase_p = (uint32_t)__builtin_amdgcn_readfirstlane((int)(r0 * C->width + c0));
                             wbase_state = master_state_at(C, wbase_p);
                         }
@@ -549,6 +566,7 @@ __global__ __launch_bounds__(RT_BLOCK, RT_WAVES_PER_EU) void k_pass(const PassPa
                     if (P.pass == 0u && P.mode == 0u) {
                         h = wbase_q + (h - wbase_h);
                         my_base_p = wbase_p;
+                        my_base_f = wbase_f;
                         my_base_state = wbase_state;
                         if (h >= P.n_items) h = RT_INVALID - 1u;   // ragged end of the strided order: nothing to do
                     }
@@ -560,6 +578,7 @@ __global__ __launch_bounds__(RT_BLOCK, RT_WAVES_PER_EU) void k_pass(const PassPa
             if (TEAMS) {
                 h = __shfl(h, team0);
                 my_base_p = __shfl(my_base_p, team0);
+                my_base_f = __shfl(my_base_f, team0);
                 my_base_state = shfl_u64(my_base_state, team0);
             }
             if (h == RT_INVALID - 1u) h = RT_INVALID;
@@ -571,10 +590,13 @@ __global__ __launch_bounds__(RT_BLOCK, RT_WAVES_PER_EU) void k_pass(const PassPa
                     acc_r = 0.f; acc_g = 0.f; acc_b = 0.f;
                     lvl = 0;
                     if (P.mode == 0u) {
-                        uint32_t grow, gcol;
-                        local_to_global(C, q, grow, gcol);
-                        // master PCG at this pixel: jump ahead p*(2*aa^2+1) draws (imagetracer.rs:63-81)
-                        const uint64_t s = master_jump(C, my_base_state, grow * C->width + gcol - my_base_p);
+                        uint32_t fr, lq, grow, gcol;
+                        local_to_global(C, q, fr, lq, grow, gcol);
+                        // master PCG at this pixel: jump ahead p*(2*aa^2+1) draws (imagetracer.rs:63-81),
+                        // from the chunk's first pixel (a chunk that runs into the next frame restarts at 0)
+                        const uint32_t gp = grow * C->width + gcol;
+                        const bool same = (fr == my_base_f);
+                        const uint64_t s = master_jump(C, same ? my_base_state : C->master_state0, same ? gp - my_base_p : gp);
                         mstate = s;
                         // seq = the u32 drawn after the pixel's 2*aa^2 jitter draws (imagetracer.rs:79)
                         const uint64_t sq = s * C->seq_mult + C->seq_plus;
@@ -664,9 +686,9 @@ __global__ __launch_bounds__(RT_BLOCK, RT_WAVES_PER_EU) void k_pass(const PassPa
             // the level-0 ray of sample samp-1 (every lane of the team: the master PCG stays replicated)
             ColdParams C = cold_params();
             if (P.mode == 0u) {
-                uint32_t grow, gcol;
-                local_to_global(C, q, grow, gcol);
-                primary_ray<AFFINE>(C, grow, gcol, samp - 1u, mstate, o, d);
+                uint32_t fr, lq, grow, gcol;
+                local_to_global(C, q, fr, lq, grow, gcol);
+                primary_ray<AFFINE>(C, C->frames + fr, grow, gcol, samp - 1u, mstate, o, d);
             } else {
                 const rt_ray r = C->in_rays[q];
                 o = {r.origin[0], r.origin[1], r.origin[2]};

@@ -443,3 +443,33 @@ def test_c5_random_spheres_10002_shapes():
     assert_bit_equal(g.cpu().numpy(), ref, "random spheres")
     for k in COUNTERS:
         assert gs[k] == rs[k], k
+
+
+def test_render_frames_animation_in_one_launch():
+    """rt_render_frames: frames with different cameras share one launch; each equals its own fire_all_rays."""
+    import torch
+    w, h = 150, 90               # 13500 pixels per frame: chunks of 64 run across frame boundaries
+    world = demo_world()
+    rr = ra.PathTracer(world, ra.BLACK, 5, 3, 2)
+    angles = [0.0, 10.0, 200.0, 90.0, 45.0]
+    cams = [demo_camera(w, h, a) for a in angles]
+    refs = [oracle_image(world, c, rr, w, h) for c in cams]
+    lib, dev = _abi.lib(), world.device()
+    arr = (_abi.rt_camera * len(cams))(*[flatten_camera(c) for c in cams])
+    r = rr.flatten()
+    for schedule in [(), (0,), (4, 9)]:
+        for part in [None, _abi.rt_partition(1, 3, 2)]:
+            dev.set_schedule(schedule)
+            n_local = lib.rt_partition_pixels(w, h, C.byref(part) if part else None)
+            outs = [torch.zeros((n_local, 3), dtype=torch.float32, device="cuda") for _ in cams]
+            ptrs = (C.c_void_p * len(cams))(*[o.data_ptr() for o in outs])
+            st = _abi.rt_stats()
+            _abi.check(lib.rt_render_frames(dev.handle, arr, len(cams), C.byref(r), w, h, 42, 54, 1,
+                                            C.byref(part) if part else None, ptrs,
+                                            torch.cuda.current_stream().cuda_stream, C.byref(st)))
+            dev.set_schedule(())
+            rows = list(range(h)) if part is None else [y for y in range(h) if (y // 2) % 3 == 1]
+            for f, (ref, rs) in enumerate(refs):
+                assert_bit_equal(outs[f].cpu().numpy().reshape(len(rows), w, 3), ref[rows], f"frame {f} schedule={schedule}")
+            if part is None:
+                assert st.rays == sum(rs["rays"] for _, rs in refs)
