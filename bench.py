@@ -1,9 +1,12 @@
 #!/usr/bin/env python3
 """bench.py — headline benchmark: path samples/s of examples/demo.yml, pathtracer, 1920x1080.
 
-A step = one ImageTracer::fire_all_rays pass (one frame) with the scene already resident in HBM
-and the image left in HBM.  N GPUs split the SAME frame by row tiles dealt round-robin (strong
-scaling), one process per GPU, one RCCL gather of the parts into rank 0's image per step.
+A step = one ImageTracer::fire_all_rays pass (one whole frame) with the scene already resident in
+HBM and the image left in HBM.  Steps are issued as launches of B frames (rt_render_frames: the
+frames of a launch share one pixel queue on the GPU) over F HIP streams, so B*F frames are in
+flight; every frame is rendered in full, nothing is cached between frames.  N GPUs split EVERY
+frame by row tiles dealt round-robin (strong scaling), one process per GPU, and one RCCL gather
+per launch brings the parts to rank 0, where rt_unpack_parts assembles the images.
 
   python bench.py --gpus 1 --steps K --warmup W
   python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
@@ -23,17 +26,11 @@ WIDTH, HEIGHT, AA = 1920, 1080, 1
 NUM_OF_RAYS, MAX_DEPTH, RR_LIMIT = 10, 3, 3
 INIT_STATE, INIT_SEQ = 42, 54
 EXPECTED_RAYS = 44180520            # oracle (strict math) ray count of this exact frame; tests/test_gpu_parity.py
-PEAK_FP32_VECTOR_TFLOPS = 157.3     # MI355X_MICROARCH.md: spec, FMA counted as 2 flop
-PEAK_STRICT_NOFMA_TFLOPS = 78.6     # same issue rate with unfused mul/add (reference forbids FMA)
-
-
-def partition_rows(height, part, n_parts, tile_rows):
-    """Rows of `part` (host mirror of part_rows() in csrc/rt_host.inc)."""
-    rows = []
-    n_tiles = (height + tile_rows - 1) // tile_rows
-    for j in range(part, n_tiles, n_parts):
-        rows.extend(range(j * tile_rows, min((j + 1) * tile_rows, height)))
-    return rows
+PEAK_FP32_VECTOR_TFLOPS = 157.3     # MI355X_MICROARCH.md: spec, packed FMA counted as 2 flop
+PEAK_STRICT_NOFMA_TFLOPS = 78.6     # same issue rate with unfused mul/add (the reference forbids FMA contraction)
+# HBM bytes per launch of the default configuration, from profiles/ (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE,
+# FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for gfx950); None until measured for this build
+TRAFFIC_BYTES_PER_FRAME = None
 
 
 def flops_per_ray(n_spheres, n_planes):
@@ -57,13 +54,15 @@ def cpu_baseline(flat, cam, rr, threads):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=200)
-    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--steps", type=int, default=240)
+    ap.add_argument("--warmup", type=int, default=24)
     ap.add_argument("--tile-rows", type=int, default=1)
-    ap.add_argument("--inflight", type=int, default=3, help="frames in flight on separate HIP streams (1..4)")
+    ap.add_argument("--inflight", type=int, default=3, help="launches in flight on separate HIP streams (1..4)")
+    ap.add_argument("--frames-per-launch", type=int, default=4, help="frames rendered by one rt_render_frames launch")
     ap.add_argument("--schedule", choices=["auto", "passes", "onepass"], default="auto",
                     help="rt_scene_set_schedule: 'passes' = short passes (lowest single-frame latency), 'onepass' = one "
-                         "pass per frame (best throughput with frames in flight); auto = onepass iff --inflight > 1")
+                         "pass per launch (best throughput with many frames in flight); auto = onepass unless "
+                         "--inflight 1 --frames-per-launch 1")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
@@ -90,49 +89,63 @@ def main():
     cam = flatten_camera(demo_camera(WIDTH, HEIGHT))
     rr = ra.PathTracer(scene, ra.BLACK, NUM_OF_RAYS, MAX_DEPTH, RR_LIMIT).flatten()
     dev = scene.device()          # World resident in HBM before the timed region
-    onepass = args.schedule == "onepass" or (args.schedule == "auto" and args.inflight > 1)
+    F = max(1, min(args.inflight, 4))
+    B = max(1, min(args.frames_per_launch, 64))
+    onepass = args.schedule == "onepass" or (args.schedule == "auto" and (F > 1 or B > 1))
     dev.set_schedule((0,) if onepass else ())
-    stream = torch.cuda.current_stream()
 
     part = _abi.rt_partition(rank, world_size, args.tile_rows)
     sizes = [lib.rt_partition_pixels(WIDTH, HEIGHT, C.byref(_abi.rt_partition(p, world_size, args.tile_rows)))
              for p in range(world_size)]
     stride = max(sizes)
-    # F frames in flight: frame i runs on stream i % F with its own part / gather / image buffers, so
-    # the long single-pixel dependency chains at the end of frame i overlap the bulk of frame i+1
-    # (and, for N > 1, gather(i) overlaps render(i+1)).  Every frame is rendered in full.
-    F = max(1, min(args.inflight, 4))
+    # Launch l renders frames [l*B, l*B + n) on stream l % F with that slot's own buffers, so the long
+    # single-pixel dependency chains at the end of one launch overlap the bulk of the next ones (and,
+    # for N > 1, gather(l) overlaps render(l+1)).
     streams = [torch.cuda.Stream() for _ in range(F)]
-    bufs = [torch.zeros((stride, 3), dtype=torch.float32, device="cuda") for _ in range(F)]
-    images = [torch.zeros((HEIGHT, WIDTH, 3), dtype=torch.float32, device="cuda") for _ in range(F)]
-    gathered = None
-    if world_size > 1 and rank == 0:
-        gathered = [torch.zeros((world_size, stride, 3), dtype=torch.float32, device="cuda") for _ in range(F)]
+    cams = (_abi.rt_camera * B)(*([cam] * B))
+    images = [torch.zeros((B, HEIGHT, WIDTH, 3), dtype=torch.float32, device="cuda") for _ in range(F)]
+    bufs = gathered = None
+    if world_size > 1:
+        bufs = [torch.zeros((B, stride, 3), dtype=torch.float32, device="cuda") for _ in range(F)]
+        if rank == 0:
+            gathered = [torch.zeros((world_size, B, stride, 3), dtype=torch.float32, device="cuda") for _ in range(F)]
 
-    def render(slot, stats=None):
-        out = bufs[slot] if world_size > 1 else images[slot].view(-1, 3)
-        _abi.check(lib.rt_render(dev.handle, C.byref(cam), C.byref(rr), WIDTH, HEIGHT, INIT_STATE, INIT_SEQ, AA,
-                                 C.byref(part), out.data_ptr(), streams[slot].cuda_stream, stats))
+    def out_ptrs(slot, n):
+        t = bufs[slot] if world_size > 1 else images[slot]
+        return (C.c_void_p * n)(*[t[b].data_ptr() for b in range(n)])
 
-    def step(i, ev=None):
-        slot = i % F
+    def launch(l, n, ev=None, stats=None):
+        slot = l % F
         st = streams[slot]
         with torch.cuda.stream(st):
             if ev:
                 ev[0].record(st)
-            render(slot)
+            _abi.check(lib.rt_render_frames(dev.handle, cams, n, C.byref(rr), WIDTH, HEIGHT, INIT_STATE, INIT_SEQ, AA,
+                                            C.byref(part), out_ptrs(slot, n), st.cuda_stream, stats))
             if ev:
                 ev[1].record(st)
             if world_size > 1:
                 # the collective runs on RCCL's stream after st's render; work.wait() makes st (not the
-                # host) wait for it, so the slot's buffers are free again when st reaches its next frame
+                # host) wait for it, so the slot's buffers are free again when st reaches its next launch
                 if rank == 0:
                     glist = list(gathered[slot].unbind(0))
                     dist.gather(bufs[slot], gather_list=glist, dst=0, async_op=True).wait()
-                    _abi.check(lib.rt_unpack_parts(gathered[slot].data_ptr(), stride, world_size, args.tile_rows,
-                                                   WIDTH, HEIGHT, images[slot].data_ptr(), st.cuda_stream))
+                    for b in range(n):
+                        _abi.check(lib.rt_unpack_parts(gathered[slot][0, b].data_ptr(), B * stride, world_size,
+                                                       args.tile_rows, WIDTH, HEIGHT, images[slot][b].data_ptr(),
+                                                       st.cuda_stream))
                 else:
                     dist.gather(bufs[slot], dst=0, async_op=True).wait()
+
+    def run(steps, events=None):
+        l = 0
+        done = 0
+        while done < steps:
+            n = min(B, steps - done)
+            launch(l, n, events[l] if events is not None else None)
+            done += n
+            l += 1
+        return l
 
     def sync_all():
         torch.cuda.synchronize()
@@ -140,45 +153,47 @@ def main():
             dist.barrier()
             torch.cuda.synchronize()
 
-    # one instrumented launch: ray counters of this rank's part (deterministic, same every step)
+    # one instrumented single-frame launch: ray counters of this rank's part (deterministic, same every step)
     st = _abi.rt_stats()
-    render(0, C.byref(st))
+    launch(0, 1, stats=C.byref(st))
     my_rays = st.rays
     if world_size == 1 and my_rays != EXPECTED_RAYS:
         raise SystemExit(f"ray counter {my_rays} != {EXPECTED_RAYS} (oracle, World::ray_intersection calls of this frame)")
-    torch.cuda.synchronize()
-
-    for i in range(args.warmup):
-        step(i)
     sync_all()
-    events = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
+
+    run(args.warmup)
+    sync_all()
+    n_launches = (args.steps + B - 1) // B
+    events = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(n_launches)]
     t0 = time.perf_counter()
-    for i in range(args.steps):
-        step(i, events[i])
+    run(args.steps, events)
     sync_all()
     dt = time.perf_counter() - t0
 
-    # per-launch latency (start -> end of each frame's kernels on its own stream; overlapping frames
-    # stretch each other) and the device-side span of the whole timed region / K = effective duration
-    latency_ms = sum(a.elapsed_time(b) for a, b in events) / max(1, args.steps)
+    # per-launch latency (start -> end of the launch's kernels on its own stream; launches in flight
+    # stretch each other) and the device-side span of the whole timed region / launches = the effective
+    # duration of one launch
+    latency_ms = sum(a.elapsed_time(b) for a, b in events) / n_launches
     span_ms = max(events[0][0].elapsed_time(e[1]) for e in events[-F:])
-    kernel_ms = span_ms / max(1, args.steps)
-    t = torch.tensor([dt, kernel_ms, float(my_rays), latency_ms], dtype=torch.float64, device="cuda")
+    launch_ms = span_ms / n_launches
+    t = torch.tensor([dt, launch_ms, float(my_rays), latency_ms], dtype=torch.float64, device="cuda")
     if world_size > 1:
         tmax = t.clone()
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         tsum = t.clone()
         dist.all_reduce(tsum, op=dist.ReduceOp.SUM)
-        dt, kernel_ms_max, total_rays = float(tmax[0]), float(tmax[1]), float(tsum[2])
+        dt, total_rays = float(tmax[0]), float(tsum[2])
     else:
-        kernel_ms_max, total_rays = kernel_ms, float(my_rays)
+        total_rays = float(my_rays)
 
     if rank == 0:
         samples_per_step = WIDTH * HEIGHT * AA * AA
         value = samples_per_step * args.steps / dt
         fpr = flops_per_ray(dev_n_spheres(flat), dev_n_planes(flat))
-        # roofline of the dominant kernel (k_render) on THIS rank: algorithmic flops / device time
-        achieved = my_rays * fpr / (kernel_ms * 1e-3) / 1e12
+        # roofline of the dominant kernel (k_pass) on THIS rank: algorithmic flops of one launch / its
+        # effective duration (HIP events on the launch streams over the timed region)
+        frames_per_launch = args.steps / n_launches
+        achieved = my_rays * frames_per_launch * fpr / (launch_ms * 1e-3) / 1e12
         out = {
             "metric": "path samples/sec (node) demo.yml pathtracer 1080p",
             "value": value, "unit": "path samples/s", "n_gpus": world_size, "steps": args.steps,
@@ -186,15 +201,17 @@ def main():
             "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"examples/demo.yml scene (4 shapes), pathtracer n={NUM_OF_RAYS} d={MAX_DEPTH} "
                                    f"rr={RR_LIMIT}, {WIDTH}x{HEIGHT}, aa={AA}, seeds {INIT_STATE}/{INIT_SEQ}",
-                       "parallelism": f"row tiles ({args.tile_rows} rows) round-robin over {world_size} GPU(s), "
-                                      "RCCL gather to rank 0" if world_size > 1 else "1 GPU, whole frame",
+                       "parallelism": (f"row tiles ({args.tile_rows} rows) of every frame round-robin over {world_size} "
+                                       "GPU(s), RCCL gather to rank 0") if world_size > 1 else "1 GPU, whole frames",
+                       "frames_per_launch": B, "launches_in_flight": F,
+                       "schedule": "onepass" if onepass else "passes",
                        "rays_per_frame": total_rays, "rays_per_s": total_rays * args.steps / dt},
             "roofline": {"bound": "valu", "achieved": achieved, "peak": PEAK_FP32_VECTOR_TFLOPS, "unit": "TFLOP/s",
-                         "frac": achieved / PEAK_FP32_VECTOR_TFLOPS, "traffic": None,
-                         "kernel": "k_render (+k_classify)", "kernel_ms": kernel_ms, "launch_latency_ms": latency_ms,
-                         "frames_in_flight": F, "schedule": "onepass" if onepass else "passes",
-                         "rays_per_launch": my_rays,
-                         "flops_per_ray": fpr, "peak_strict_nofma": PEAK_STRICT_NOFMA_TFLOPS,
+                         "frac": achieved / PEAK_FP32_VECTOR_TFLOPS,
+                         "traffic": TRAFFIC_BYTES_PER_FRAME * frames_per_launch if TRAFFIC_BYTES_PER_FRAME else None,
+                         "kernel": "k_pass", "launch_ms": launch_ms, "launch_latency_ms": latency_ms,
+                         "rays_per_launch": my_rays * frames_per_launch, "flops_per_ray": fpr,
+                         "peak_strict_nofma": PEAK_STRICT_NOFMA_TFLOPS,
                          "frac_strict_nofma": achieved / PEAK_STRICT_NOFMA_TFLOPS},
         }
         if world_size == 1 and not args.no_cpu_baseline:

@@ -69,13 +69,16 @@ struct FrameEntry {
 };
 static_assert(sizeof(FrameEntry) == 96, "FrameEntry layout");
 
+#define RT_INLINE_FRAMES 8   // launches of up to this many frames carry their frame table in the kernarg
+
 // Everything a pass needs, passed by value (kernarg -> SGPRs).
 struct PassParams {
     uint32_t n_shapes;
     uint32_t mode;                   // 0: image render; 1: batch Renderer::solve on caller (ray, pcg)
     // frames of this launch (mode 0): item id = frame * n_per_frame + local pixel
-    const FrameEntry* frames;
+    const FrameEntry* frames;        // device table, or NULL: the frames are in frames_inline
     uint32_t n_frames, n_per_frame;
+    FrameEntry frames_inline[RT_INLINE_FRAMES];
     // renderer (src/render.rs)
     uint32_t algorithm;
     float bg[3], fg[3];
@@ -127,6 +130,13 @@ __device__ __forceinline__ ColdParams cold_params() {
     ColdParams p = (ColdParams)__builtin_amdgcn_kernarg_segment_ptr();
     asm volatile("" : "+s"(p));
     return p;
+}
+
+// Frame table entry: in the kernarg segment for small launches (no upload), else in device memory.
+__device__ __forceinline__ const FrameEntry* frame_entry(ColdParams C, uint32_t frame) {
+    const FrameEntry* tab = C->frames;
+    if (tab) return tab + frame;
+    return reinterpret_cast<const FrameEntry*>(reinterpret_cast<uintptr_t>(&C->frames_inline[0])) + frame;
 }
 
 // Saved level state accessors: STACK_LDS ? LDS : global.
@@ -514,7 +524,7 @@ __global__ __launch_bounds__(RT_BLOCK, RT_WAVES_PER_EU) void k_pass(const PassPa
                         if (P.mode == 0u) {
                             uint32_t fr, lq, gr_, gc_;
                             local_to_global(C, q, fr, lq, gr_, gc_);
-                            float* o = C->frames[fr].out + 3ull * lq;
+                            float* o = frame_entry(C, fr)->out + 3ull * lq;
                             const float inv_samples = C->inv_samples;
                             o[0] = acc_r * inv_samples;
                             o[1] = acc_g * inv_samples;
@@ -688,7 +698,7 @@ __global__ __launch_bounds__(RT_BLOCK, RT_WAVES_PER_EU) void k_pass(const PassPa
             if (P.mode == 0u) {
                 uint32_t fr, lq, grow, gcol;
                 local_to_global(C, q, fr, lq, grow, gcol);
-                primary_ray<AFFINE>(C, C->frames + fr, grow, gcol, samp - 1u, mstate, o, d);
+                primary_ray<AFFINE>(C, frame_entry(C, fr), grow, gcol, samp - 1u, mstate, o, d);
             } else {
                 const rt_ray r = C->in_rays[q];
                 o = {r.origin[0], r.origin[1], r.origin[2]};

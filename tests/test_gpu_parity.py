@@ -451,15 +451,16 @@ def test_render_frames_animation_in_one_launch():
     w, h = 150, 90               # 13500 pixels per frame: chunks of 64 run across frame boundaries
     world = demo_world()
     rr = ra.PathTracer(world, ra.BLACK, 5, 3, 2)
-    angles = [0.0, 10.0, 200.0, 90.0, 45.0]
-    cams = [demo_camera(w, h, a) for a in angles]
-    refs = [oracle_image(world, c, rr, w, h) for c in cams]
+    angles = [0.0, 10.0, 200.0, 90.0, 45.0, 30.0, 60.0, 75.0, 120.0, 300.0]   # > RT_INLINE_FRAMES: uploaded frame table
+    all_cams = [demo_camera(w, h, a) for a in angles]
+    all_refs = [oracle_image(world, c, rr, w, h) for c in all_cams]
     lib, dev = _abi.lib(), world.device()
-    arr = (_abi.rt_camera * len(cams))(*[flatten_camera(c) for c in cams])
     r = rr.flatten()
-    for schedule in [(), (0,), (4, 9)]:
+    for schedule, n_use in [((), 10), ((0,), 5), ((4, 9), 10)]:
         for part in [None, _abi.rt_partition(1, 3, 2)]:
             dev.set_schedule(schedule)
+            cams, refs = all_cams[:n_use], all_refs[:n_use]
+            arr = (_abi.rt_camera * len(cams))(*[flatten_camera(c) for c in cams])
             n_local = lib.rt_partition_pixels(w, h, C.byref(part) if part else None)
             outs = [torch.zeros((n_local, 3), dtype=torch.float32, device="cuda") for _ in cams]
             ptrs = (C.c_void_p * len(cams))(*[o.data_ptr() for o in outs])
