@@ -28,9 +28,11 @@ INIT_STATE, INIT_SEQ = 42, 54
 EXPECTED_RAYS = 44180520            # oracle (strict math) ray count of this exact frame; tests/test_gpu_parity.py
 PEAK_FP32_VECTOR_TFLOPS = 157.3     # MI355X_MICROARCH.md: spec, packed FMA counted as 2 flop
 PEAK_STRICT_NOFMA_TFLOPS = 78.6     # same issue rate with unfused mul/add (the reference forbids FMA contraction)
-# HBM bytes per launch of the default configuration, from profiles/ (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE,
-# FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for gfx950); None until measured for this build
-TRAFFIC_BYTES_PER_FRAME = None
+# HBM bytes per frame of the default configuration, from profiles/r01_rocprof_default_F3_B4.txt (rocprofv3
+# --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate passes, KB per dispatch of 4 frames: 11265 and 126180;
+# FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for gfx950): (2*11265 + 126180) KB / 4.  The
+# algorithmic minimum is the 24.9 MB image; the path is VALU-bound, not HBM-bound.
+TRAFFIC_BYTES_PER_FRAME = (2 * 11265 + 126180) * 1000 / 4
 
 
 def flops_per_ray(n_spheres, n_planes):
