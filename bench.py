@@ -66,6 +66,10 @@ def main():
                          "pass per launch (best throughput with many frames in flight); auto = onepass unless "
                          "--inflight 1 --frames-per-launch 1")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--dist-backend", choices=["nccl", "gloo"], default="nccl",
+                    help="gloo: rehearse the N > 1 path on a box with fewer GPUs than ranks (parts staged through host memory)")
+    ap.add_argument("--verify", action="store_true",
+                    help="after the run, rank 0 compares every assembled image with a whole-frame render, bit for bit")
     args = ap.parse_args()
 
     import torch
@@ -80,11 +84,15 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world_size != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world_size}: launch with torch.distributed.run")
-    torch.cuda.set_device(local_rank)
+    device = local_rank % torch.cuda.device_count() if args.dist_backend == "gloo" else local_rank
+    torch.cuda.set_device(device)
     lib = _abi.lib()
-    _abi.check(lib.rt_init(local_rank))
+    _abi.check(lib.rt_init(device))
     if world_size > 1:
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if args.dist_backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", device))
+        else:
+            dist.init_process_group("gloo")
 
     scene = demo_world()
     flat = scene.flatten()
@@ -129,15 +137,22 @@ def main():
             if world_size > 1:
                 # the collective runs on RCCL's stream after st's render; work.wait() makes st (not the
                 # host) wait for it, so the slot's buffers are free again when st reaches its next launch
-                if rank == 0:
+                if args.dist_backend == "gloo":
+                    host = bufs[slot].cpu()
+                    hlist = [torch.empty_like(host) for _ in range(world_size)] if rank == 0 else None
+                    dist.gather(host, gather_list=hlist, dst=0)
+                    if rank == 0:
+                        gathered[slot].copy_(torch.stack(hlist))
+                elif rank == 0:
                     glist = list(gathered[slot].unbind(0))
                     dist.gather(bufs[slot], gather_list=glist, dst=0, async_op=True).wait()
+                else:
+                    dist.gather(bufs[slot], dst=0, async_op=True).wait()
+                if rank == 0:
                     for b in range(n):
                         _abi.check(lib.rt_unpack_parts(gathered[slot][0, b].data_ptr(), B * stride, world_size,
                                                        args.tile_rows, WIDTH, HEIGHT, images[slot][b].data_ptr(),
                                                        st.cuda_stream))
-                else:
-                    dist.gather(bufs[slot], dst=0, async_op=True).wait()
 
     def run(steps, events=None):
         l = 0
@@ -187,6 +202,19 @@ def main():
         dt, total_rays = float(tmax[0]), float(tsum[2])
     else:
         total_rays = float(my_rays)
+
+    if args.verify and rank == 0:
+        ref = torch.zeros((HEIGHT, WIDTH, 3), dtype=torch.float32, device="cuda")
+        _abi.check(lib.rt_render(dev.handle, C.byref(cam), C.byref(rr), WIDTH, HEIGHT, INIT_STATE, INIT_SEQ, AA, None,
+                                 ref.data_ptr(), torch.cuda.current_stream().cuda_stream, None))
+        torch.cuda.synchronize()
+        n_last = args.steps - (n_launches - 1) * B     # frames of the last launch
+        for slot in range(min(F, n_launches)):
+            n_chk = n_last if slot == (n_launches - 1) % F else B
+            for b in range(n_chk):
+                if not torch.equal(images[slot][b].view(torch.int32), ref.view(torch.int32)):
+                    raise SystemExit(f"verify: image {b} of slot {slot} differs from the whole-frame render")
+        print(f"verify ok: {min(F, n_launches)} slots x up to {B} images bit-identical to a whole-frame render", file=sys.stderr)
 
     if rank == 0:
         samples_per_step = WIDTH * HEIGHT * AA * AA
