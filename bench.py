@@ -35,6 +35,15 @@ PEAK_STRICT_NOFMA_TFLOPS = 78.6     # same issue rate with unfused mul/add (the 
 TRAFFIC_BYTES_PER_FRAME = (2 * 11265 + 126180) * 1000 / 4
 
 
+def partition_rows(height, part, n_parts, tile_rows):
+    """Rows of `part` (host mirror of part_rows() in csrc/rt_host.inc)."""
+    rows = []
+    n_tiles = (height + tile_rows - 1) // tile_rows
+    for j in range(part, n_tiles, n_parts):
+        rows.extend(range(j * tile_rows, min((j + 1) * tile_rows, height)))
+    return rows
+
+
 def flops_per_ray(n_spheres, n_planes):
     """60 per sphere test, 40 per plane test, +62 hit tail, +46 shade."""
     return 60 * n_spheres + 40 * n_planes + 62 + 46

@@ -162,3 +162,39 @@ def random_spheres_world(n_spheres=10000, seed=2024, seq=1, extent=50.0):
 def random_spheres_camera(width, height):
     tr = translation((-12.0, 0.0, 3.0)) * rotation_y(to_radians(12.0))
     return PerspectiveCamera(1.0, float(F(F(width) / F(height))), tr)
+
+
+def flake_yml():
+    """The scene file `cue eval flake.cue` produces (README.md:264-268), as text in the reference's
+    scene format; parsing it with rustracer_amd.scene gives flake_world() / flake_camera()."""
+    def num(x):
+        return repr(float(x)) if float(x) != int(x) or abs(x) >= 1e16 else str(int(x))
+
+    def vec(v):
+        return "[" + ", ".join(num(c) for c in v) + "]"
+
+    lines = ["colors:"]
+    for name, rgb in (("sky", (0 / 255, 221 / 255, 255 / 255)), ("ground", (255 / 255, 142 / 255, 80 / 255)),
+                      ("flake", (95 / 255, 95 / 255, 95 / 255))):
+        lines += [f"  - name: {name}", f"    color: {vec(rgb)}"]
+    lines += ["materials:",
+              "  - name: sky", "    diffuse:", "      uniform: sky", "    uniform: WHITE",
+              "  - name: flake", "    specular:", "      uniform: flake", "    uniform: BLACK",
+              "  - name: ground", "    diffuse:", "      uniform: ground", "    uniform: BLACK",
+              "transformations:"]
+    named = [("ground", [("translation", (0, 0, -1))]),
+             ("camera", [("translation", (-2, 0, 0)), ("rotationy", 48)]),
+             ("sky", [("scaling", (100, 100, 100)), ("translation", (0, 0, 0.5))])]
+    named += [(f"flake_{i}", e) for i, e in enumerate(_flake_compose_lists())]
+    for name, entries in named:
+        lines += [f"  - name: {name}", "    compose:"]
+        for kind, arg in entries:
+            lines.append(f"      - {kind}: {vec(arg) if isinstance(arg, tuple) else num(arg)}")
+    lines += ["camera:", '  type: "perspective"', "  ratio: RATIO", "  distance: DISTANCE", "  transformation: camera",
+              "shapes:",
+              "  - shape: sphere", "    material: sky", "    transformation: sky",
+              "  - shape: plane", "    material: ground", "    transformation: ground",
+              "  - shape: sphere", "    material: flake", "    transformation: IDENTITY"]
+    for i in range(len(named) - 3):
+        lines += ["  - shape: sphere", "    material: flake", f"    transformation: flake_{i}"]
+    return "\n".join(lines) + "\n"
