@@ -20,18 +20,6 @@ namespace rtd {
 // HBM layout of the flattened World
 // ---------------------------------------------------------------------------------------------
 
-// One shape = 160 B, 16-B aligned, read with wave-uniform (scalar) loads in the closest-hit scan
-// and with per-lane vector loads once per ray for the winner.
-struct __attribute__((aligned(16))) DShape {
-    float inv[16];      // Transformation.invm, row-major
-    float m[16];        // Transformation.m, row-major
-    uint32_t kind;      // RT_SHAPE_*
-    uint32_t material;  // index into DMaterial table
-    uint32_t needs_uv;  // 1 if either pigment of the material reads (u,v)
-    uint32_t pad[5];
-};
-static_assert(sizeof(DShape) == 160, "DShape layout");
-
 // Scan table entry (64 B): what the closest-hit loop needs per shape, read wave-uniformly
 // (LDS broadcast when the table is staged, scalar loads otherwise).
 struct __attribute__((aligned(16))) DScan {
@@ -139,44 +127,15 @@ __device__ __forceinline__ Vec3 xform_vector(const float* __restrict__ M, float 
     r.z = M[8] * x + M[9] * y + M[10] * z;
     return r;
 }
-// T*Normal: inverse matrix transposed (transformation.rs:145-161); I = Transformation.invm.
-__device__ __forceinline__ Vec3 xform_normal(const float* __restrict__ I, float x, float y, float z) {
-    Vec3 r;
-    r.x = I[0] * x + I[4] * y + I[8] * z;
-    r.y = I[1] * x + I[5] * y + I[9] * z;
-    r.z = I[2] * x + I[6] * y + I[10] * z;
-    return r;
-}
-
 // ---------------------------------------------------------------------------------------------
 // Shape::ray_intersection, candidate part: only `t` is produced here; the HitRecord of the final
 // winner is built once by hit_record() below (result-identical: World keeps one record).
 // ---------------------------------------------------------------------------------------------
 
-// Sphere::ray_intersection up to first_hit_t (src/shape.rs:112-133).
-__device__ __forceinline__ bool sphere_t(Vec3 o, Vec3 d, float tmin, float tmax, float& t_out) {
-    const float a = d.x * d.x + d.y * d.y + d.z * d.z;
-    const float b = 2.0f * (o.x * d.x + o.y * d.y + o.z * d.z);
-    const float c = (o.x * o.x + o.y * o.y + o.z * o.z) - 1.0f;
-    const float delta = b * b - 4.0f * a * c;
-    if (delta <= 0.0f) return false;
-    const float sqrt_delta = __builtin_sqrtf(delta);
-    const float a2 = 2.0f * a;
-    const float t1 = (-b - sqrt_delta) / a2;
-    if ((t1 > tmin) && (t1 < tmax)) {
-        t_out = t1;
-        return true;
-    }
-    const float t2 = (-b + sqrt_delta) / a2;
-    if ((t2 > tmin) && (t2 < tmax)) {
-        t_out = t2;
-        return true;
-    }
-    return false;
-}
-
-// The same value and the same decision without control flow: the roots are computed for every lane
-// (sqrt of a negative delta is NaN and fails every comparison; delta <= 0 is rejected explicitly).
+// Sphere::ray_intersection up to first_hit_t (src/shape.rs:112-133) and Plane::ray_intersection up to t
+// (src/shape.rs:196-204), the reference's values and decisions without control flow: the roots are
+// computed for every lane (sqrt of a negative delta is NaN and fails every comparison; delta <= 0 is
+// rejected explicitly; a NaN plane t passes both range tests exactly as in the reference).
 __device__ __forceinline__ bool sphere_t_nb(Vec3 o, Vec3 d, float tmin, float tmax, float& t_out) {
     const float a = d.x * d.x + d.y * d.y + d.z * d.z;
     const float b = 2.0f * (o.x * d.x + o.y * d.y + o.z * d.z);
@@ -197,85 +156,14 @@ __device__ __forceinline__ bool plane_t_nb(Vec3 o, Vec3 d, float tmin, float tma
     return !(__builtin_fabsf(d.z) < 1e-5f) && !((t <= tmin) || (t >= tmax));
 }
 
-// Plane::ray_intersection up to t (src/shape.rs:196-204).
-__device__ __forceinline__ bool plane_t(Vec3 o, Vec3 d, float tmin, float tmax, float& t_out) {
-    if (__builtin_fabsf(d.z) < 1e-5f) return false;
-    const float t = -o.z / d.z;
-    if ((t <= tmin) || (t >= tmax)) return false;
-    t_out = t;
-    return true;
-}
-
 struct HitRec {
     Vec3 world_point;
     Vec3 normal;
     float u, v;
 };
 
-// The HitRecord fields of the winning shape (src/shape.rs:134-142, :205-213), with
-// sphere_normal (:88-95), sphere_point_to_uv (:101-108), plane_normal (:175-182),
-// plane_point_to_uv (:187-192).  S points at the winner's DShape (per-lane address).
-template <bool AFFINE>
-__device__ __forceinline__ HitRec hit_record(const DShape* __restrict__ S, Vec3 ro, Vec3 rd, float t, bool want_uv) {
-    HitRec h;
-    const Vec3 o = xform_point<AFFINE>(S->inv, ro.x, ro.y, ro.z);
-    const Vec3 d = xform_vector(S->inv, rd.x, rd.y, rd.z);
-    // inv_ray.at(t) (src/ray.rs:26-28)
-    const float hx = o.x + d.x * t, hy = o.y + d.y * t, hz = o.z + d.z * t;
-    h.world_point = xform_point<AFFINE>(S->m, hx, hy, hz);
-    h.u = 0.0f;
-    h.v = 0.0f;
-    if (S->kind == RT_SHAPE_SPHERE) {
-        const float dp = hx * d.x + hy * d.y + hz * d.z;
-        float nx = hx, ny = hy, nz = hz;
-        if (!(dp < 0.0f)) { nx = -nx; ny = -ny; nz = -nz; }
-        h.normal = xform_normal(S->inv, nx, ny, nz);
-        if (want_uv) {
-            float u = rt_atan2f(hy, hx) / 6.2831854820251465f;  // 2.0 * PI in f32
-            const float v = rt_acosf(hz) / 3.1415927410125732f; // PI in f32
-            if (u < 0.0f) u += 1.0f;
-            h.u = u;
-            h.v = v;
-        }
-    } else {
-        const float dp = 0.0f * d.x + 0.0f * d.y + 1.0f * d.z;
-        float nx = 0.0f, ny = 0.0f, nz = 1.0f;
-        if (!(dp < 0.0f)) { nx = -0.0f; ny = -0.0f; nz = -1.0f; }
-        h.normal = xform_normal(S->inv, nx, ny, nz);
-        if (want_uv) {
-            h.u = hx - __builtin_floorf(hx);
-            h.v = hy - __builtin_floorf(hy);
-        }
-    }
-    return h;
-}
-
-// World::ray_intersection (src/world.rs:32-50): linear scan in insertion order, strict `<`, so the
-// earliest shape wins ties; the first hit is taken unconditionally (even t = NaN).
-// `shapes` and `n_shapes` are wave-uniform, so the table is read through scalar loads.
-template <bool AFFINE>
-__device__ __forceinline__ int closest_hit(const DShape* __restrict__ shapes, uint32_t n_shapes, Vec3 ro, Vec3 rd,
-                                           float tmin, float tmax, float& best_t) {
-    int best = -1;
-    best_t = 0.0f;
-    for (uint32_t i = 0; i < n_shapes; ++i) {
-        const DShape* __restrict__ S = shapes + i;
-        const Vec3 o = xform_point<AFFINE>(S->inv, ro.x, ro.y, ro.z);
-        const Vec3 d = xform_vector(S->inv, rd.x, rd.y, rd.z);
-        float t = 0.0f;
-        bool hit;
-        if (S->kind == RT_SHAPE_SPHERE) hit = sphere_t(o, d, tmin, tmax, t);
-        else hit = plane_t(o, d, tmin, tmax, t);
-        if (hit && (best < 0 || t < best_t)) {
-            best = (int)i;
-            best_t = t;
-        }
-    }
-    return best;
-}
-
 // ---------------------------------------------------------------------------------------------
-// The same, on the split layout (DScan / DMRows / DWRows) used by the render passes
+// Transformation * {Point, Vector, Normal} on matrix rows held in registers (DScan / DMRows / DWRows)
 // ---------------------------------------------------------------------------------------------
 struct Rows3 { float4 r0, r1, r2; };
 __device__ __forceinline__ Rows3 load_rows(const float* __restrict__ p) {
@@ -317,34 +205,11 @@ __device__ __forceinline__ Vec3 rows_normal(const Rows3& I, float x, float y, fl
     return r;
 }
 
-// World::ray_intersection (src/world.rs:32-50) over a DScan table that every lane reads at the
-// same index (LDS broadcast or scalar loads): linear scan, strict `<`, earliest shape wins ties.
-template <bool AFFINE>
-__device__ __forceinline__ int scan_closest_hit(const DScan* __restrict__ scan, const DWRows* __restrict__ wrows,
-                                                uint32_t n_shapes, Vec3 ro, Vec3 rd, float tmin, float tmax,
-                                                float& best_t) {
-    int best = -1;
-    best_t = 0.0f;
-    for (uint32_t i = 0; i < n_shapes; ++i) {
-        const DScan* __restrict__ S = scan + i;
-        const Rows3 R = load_rows(S->inv);
-        const uint32_t kind = (uint32_t)__builtin_amdgcn_readfirstlane((int)S->kind);
-        const Vec3 o = rows_point<AFFINE>(R, AFFINE ? nullptr : wrows[i].inv_w, ro.x, ro.y, ro.z);
-        const Vec3 d = rows_vector(R, rd.x, rd.y, rd.z);
-        float t = 0.0f;
-        bool hit;
-        if (kind == RT_SHAPE_SPHERE) hit = sphere_t(o, d, tmin, tmax, t);
-        else hit = plane_t(o, d, tmin, tmax, t);
-        if (hit && (best < 0 || t < best_t)) {
-            best = (int)i;
-            best_t = t;
-        }
-    }
-    return best;
-}
-
-// The same scan, G shapes per iteration (loads of a group are issued together) and without
-// control flow inside a shape test; also returns the winner's object-space ray and kind.
+// World::ray_intersection (src/world.rs:32-50) over a DScan table that every lane reads at the same
+// index (LDS broadcast or scalar loads): linear scan in insertion order, strict `<`, so the earliest
+// shape wins ties and the first hit is taken unconditionally (even t = NaN).  G shapes per iteration
+// (the loads of a group are issued together), no control flow inside a shape test; also returns the
+// winner's object-space ray and kind.
 template <bool AFFINE, int G>
 __device__ __forceinline__ int scan_closest_hit_g(const DScan* __restrict__ scan, const DWRows* __restrict__ wrows,
                                                   uint32_t n_shapes, Vec3 ro, Vec3 rd, float tmin, float tmax,

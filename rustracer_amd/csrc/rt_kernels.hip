@@ -932,7 +932,9 @@ __global__ __launch_bounds__(RT_BLOCK) void k_intersect(const DScan* __restrict_
     const Vec3 ro = {r.origin[0], r.origin[1], r.origin[2]};
     const Vec3 rd = {r.dir[0], r.dir[1], r.dir[2]};
     float t;
-    const int best = scan_closest_hit<AFFINE>(scan, wrows, n_shapes, ro, rd, r.tmin, r.tmax, t);
+    Vec3 lo, ld;
+    uint32_t bkind;
+    const int best = scan_closest_hit_g<AFFINE, 2>(scan, wrows, n_shapes, ro, rd, r.tmin, r.tmax, t, lo, ld, bkind);
     rt_hit h;
     h.hit = 0; h.shape = 0; h.t = 0.f;
     h.world_point[0] = h.world_point[1] = h.world_point[2] = 0.f;
