@@ -68,8 +68,8 @@ def main():
     ap.add_argument("--steps", type=int, default=240)
     ap.add_argument("--warmup", type=int, default=24)
     ap.add_argument("--tile-rows", type=int, default=1)
-    ap.add_argument("--inflight", type=int, default=3, help="launches in flight on separate HIP streams (1..4)")
-    ap.add_argument("--frames-per-launch", type=int, default=4, help="frames rendered by one rt_render_frames launch")
+    ap.add_argument("--inflight", type=int, default=2, help="launches in flight on separate HIP streams (1..4)")
+    ap.add_argument("--frames-per-launch", type=int, default=16, help="frames rendered by one rt_render_frames launch")
     ap.add_argument("--schedule", choices=["auto", "passes", "onepass"], default="auto",
                     help="rt_scene_set_schedule: 'passes' = short passes (lowest single-frame latency), 'onepass' = one "
                          "pass per launch (best throughput with many frames in flight); auto = onepass unless "
