@@ -7,8 +7,9 @@
  * SURVEY.md §8c iii).  Discrete decisions downstream of these calls (checker parity, texel
  * index, next-hit selection) re-route a pixel's whole PCG stream, so host oracle and device
  * kernel must agree to the last bit.  This header fixes that by construction: every function is
- * evaluated in IEEE binary64 with plain mul/add/div/sqrt (no FMA contraction: build with
- * -ffp-contract=off on both sides) and rounded once to binary32.  The binary64 evaluation error
+ * evaluated in IEEE binary64 with plain mul/add/div/sqrt plus EXPLICIT fused multiply-adds
+ * (rt_fma_d; no implicit contraction: build with -ffp-contract=off on both sides) and rounded once
+ * to binary32.  The binary64 evaluation error
  * is < 2^-48 relative, so the result is the correctly rounded f32 value except when the exact
  * value lies within ~2^-24 ulp of a rounding boundary.
  *
@@ -47,60 +48,60 @@ RT_HD float rt_maxf(float a, float b) {
 /* ---- sin / cos ---------------------------------------------------------------------------- */
 
 /* Cody-Waite reduction by pi/2 in three 33-bit pieces (n*RT_PIO2_1 is exact for |n| < 2^20),
- * then Taylor kernels on |r| <= pi/4.  Accurate domain |x| <= 1e6; the hot path only calls it
- * with x = 2*pi*rf, rf in [0,1]. */
+ * then Taylor kernels on |r| <= pi/4, Horner steps fused (rt_fma_d).  Accurate domain |x| <= 1e6;
+ * the hot path only calls it with x = 2*pi*rf, rf in [0,1]. */
 #define RT_INV_PIO2 0.6366197723675814      /* 2/pi                                        */
 #define RT_PIO2_1 1.5707963267341256        /* 0x1.921fb54400000p+0  first 33 bits of pi/2 */
 #define RT_PIO2_2 6.077100506303966e-11     /* 0x1.0b4611a600000p-34 next 33 bits          */
 #define RT_PIO2_3 2.0222662487959506e-21    /* 0x1.3198a2e037073p-69 remainder             */
 
 RT_HD double rt_rint_d(double x) { return __builtin_rint(x); }
+/* Correctly rounded fused multiply-add in binary64: v_fma_f64 on the device, fma() (hardware FMA
+ * through glibc's ifunc where the CPU has it, exact software otherwise) on the host.  Fusion here
+ * is part of the definition of these functions; the reference's own f32 arithmetic is never fused. */
+RT_HD double rt_fma_d(double a, double b, double c) { return __builtin_fma(a, b, c); }
 
-RT_HD double rt_ksin_d(double r) {
-    const double z = r * r;
-    double p = -8.22063524662433e-18;        /* -1/19! */
-    p = p * z + 2.8114572543455206e-15;      /*  1/17! */
-    p = p * z - 7.647163731819816e-13;       /* -1/15! */
-    p = p * z + 1.6059043836821613e-10;      /*  1/13! */
-    p = p * z - 2.505210838544172e-08;       /* -1/11! */
-    p = p * z + 2.7557319223985893e-06;      /*  1/9!  */
-    p = p * z - 0.0001984126984126984;       /* -1/7!  */
-    p = p * z + 0.008333333333333333;        /*  1/5!  */
-    p = p * z - 0.16666666666666666;         /* -1/3!  */
-    return r + (r * z) * p;
+/* sin(r) = r + r^3 * P(r^2), Taylor through r^15: truncation < 4.7e-17 on |r| <= pi/4. */
+RT_HD double rt_ksin_d(double r, double z) {
+    double p = -7.647163731819816e-13;                /* -1/15! */
+    p = rt_fma_d(p, z, 1.6059043836821613e-10);       /*  1/13! */
+    p = rt_fma_d(p, z, -2.505210838544172e-08);       /* -1/11! */
+    p = rt_fma_d(p, z, 2.7557319223985893e-06);       /*  1/9!  */
+    p = rt_fma_d(p, z, -0.0001984126984126984);       /* -1/7!  */
+    p = rt_fma_d(p, z, 0.008333333333333333);         /*  1/5!  */
+    p = rt_fma_d(p, z, -0.16666666666666666);         /* -1/3!  */
+    return rt_fma_d(r * z, p, r);
 }
 
-RT_HD double rt_kcos_d(double r) {
-    const double z = r * r;
-    double p = 1.5619206968586225e-16;       /*  1/18! */
-    p = p * z - 4.779477332387385e-14;       /* -1/16! */
-    p = p * z + 1.1470745597729725e-11;      /*  1/14! */
-    p = p * z - 2.08767569878681e-09;        /* -1/12! */
-    p = p * z + 2.755731922398589e-07;       /*  1/10! */
-    p = p * z - 2.48015873015873e-05;        /* -1/8!  */
-    p = p * z + 0.001388888888888889;        /*  1/6!  */
-    p = p * z - 0.041666666666666664;        /* -1/4!  */
-    p = p * z + 0.5;                         /*  1/2!  */
-    return 1.0 - z * p;
+/* cos(r) = 1 + r^2 * Q(r^2), Taylor through r^16: truncation < 2e-18 on |r| <= pi/4. */
+RT_HD double rt_kcos_d(double z) {
+    double p = 4.779477332387385e-14;                 /*  1/16! */
+    p = rt_fma_d(p, z, -1.1470745597729725e-11);      /* -1/14! */
+    p = rt_fma_d(p, z, 2.08767569878681e-09);         /*  1/12! */
+    p = rt_fma_d(p, z, -2.755731922398589e-07);       /* -1/10! */
+    p = rt_fma_d(p, z, 2.48015873015873e-05);         /*  1/8!  */
+    p = rt_fma_d(p, z, -0.001388888888888889);        /* -1/6!  */
+    p = rt_fma_d(p, z, 0.041666666666666664);         /*  1/4!  */
+    p = rt_fma_d(p, z, -0.5);                         /* -1/2!  */
+    return rt_fma_d(z, p, 1.0);
 }
 
-/* sin and cos of an f32 argument, each rounded once to f32. */
+/* sin and cos of an f32 argument, each rounded once to f32 (the quadrant's sign change and swap
+ * commute with that rounding). */
 RT_HD void rt_sincosf(float xf, float* s, float* c) {
     const double x = (double)xf;
     const double fn = rt_rint_d(x * RT_INV_PIO2);
-    double r = x - fn * RT_PIO2_1;
-    r = r - fn * RT_PIO2_2;
-    r = r - fn * RT_PIO2_3;
-    const double ks = rt_ksin_d(r);
-    const double kc = rt_kcos_d(r);
-    const int q = (int)((long long)fn & 3LL);
-    double sv, cv;
-    if (q == 0) { sv = ks; cv = kc; }
-    else if (q == 1) { sv = kc; cv = -ks; }
-    else if (q == 2) { sv = -ks; cv = -kc; }
-    else { sv = -kc; cv = ks; }
-    *s = (float)sv;
-    *c = (float)cv;
+    double r = rt_fma_d(-fn, RT_PIO2_1, x);
+    r = rt_fma_d(-fn, RT_PIO2_2, r);
+    r = rt_fma_d(-fn, RT_PIO2_3, r);
+    const double z = r * r;
+    const float ks = (float)rt_ksin_d(r, z);
+    const float kc = (float)rt_kcos_d(z);
+    const int q = (int)fn & 3;
+    const float sv = (q & 1) ? kc : ks;
+    const float cv = (q & 1) ? ks : kc;
+    *s = (q & 2) ? -sv : sv;                  /* q = 2, 3: sin < 0 side */
+    *c = ((q + 1) & 2) ? -cv : cv;            /* q = 1, 2 */
 }
 
 RT_HD float rt_sinf(float x) { float s, c; rt_sincosf(x, &s, &c); return s; }
