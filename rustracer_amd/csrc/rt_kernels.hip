@@ -94,6 +94,8 @@ struct PassParams {
     uint64_t seq_mult, seq_plus;          // master jump by 2*aa^2 draws (to the pixel's seq draw)
     // partition (row tiles dealt round-robin)
     uint32_t part, n_parts, tile_rows;
+    // exact u32 division by invariant divisors (Granlund-Montgomery, host: magic_u32): width, n_per_frame, tile_rows
+    uint32_t mg_width[3], mg_npf[3], mg_tile[3];
     uint32_t n_items;                // n_frames * (pixels of this part) / solve items
     uint32_t n_in0;                  // length of pass 0's (virtual) queue: n_items, or whole 64-pixel granules
     uint32_t perm_stride;            // 0, or granules per stratum of the pass-0 queue order (see perm_entry)
@@ -179,15 +181,21 @@ __device__ __forceinline__ uint32_t perm_entry(uint32_t h, uint32_t stride) {
     return (((g & 63u) * stride + (g >> 6)) << 6) | (h & 63u);
 }
 
+// n / d for every u32 n, d >= 1, with mg = {m', sh1, sh2} of d: one mul_hi instead of a ~25-instruction expansion
+__device__ __forceinline__ uint32_t div_magic(uint32_t n, uint32_t m, uint32_t sh1, uint32_t sh2) {
+    const uint32_t t1 = __umulhi(m, n);
+    return (t1 + ((n - t1) >> sh1)) >> sh2;
+}
+
 // local pixel -> global (row, col) through the row-tile partition
 __device__ __forceinline__ void local_to_global(ColdParams P, uint32_t item, uint32_t& frame, uint32_t& lq,
                                                 uint32_t& grow, uint32_t& gcol) {
     const uint32_t width = P->width, tile_rows = P->tile_rows, npf = P->n_per_frame;
-    frame = (P->n_frames > 1u) ? item / npf : 0u;
+    frame = (P->n_frames > 1u) ? div_magic(item, P->mg_npf[0], P->mg_npf[1], P->mg_npf[2]) : 0u;
     lq = item - frame * npf;
-    const uint32_t lrow = lq / width;
+    const uint32_t lrow = div_magic(lq, P->mg_width[0], P->mg_width[1], P->mg_width[2]);
     gcol = lq - lrow * width;
-    const uint32_t tile = lrow / tile_rows;
+    const uint32_t tile = (tile_rows > 1u) ? div_magic(lrow, P->mg_tile[0], P->mg_tile[1], P->mg_tile[2]) : lrow;
     grow = (tile * P->n_parts + P->part) * tile_rows + (lrow - tile * tile_rows);
 }
 
@@ -198,12 +206,18 @@ __device__ __forceinline__ void primary_ray(ColdParams P, const FrameEntry* __re
                                             uint32_t samp, uint64_t& mstate, Vec3& ro, Vec3& rd) {
     const uint32_t aa = P->aa;
     const uint64_t minc = P->master_inc;
-    const uint32_t sub_row = samp / aa;
-    const uint32_t sub_col = samp - sub_row * aa;
     const float rf0 = pcg_random_float(mstate, minc);
     const float rf1 = pcg_random_float(mstate, minc);
-    const float u_pixel = ((float)sub_row + rf0) / (float)aa;
-    const float v_pixel = ((float)sub_col + rf1) / (float)aa;
+    float u_pixel, v_pixel;
+    if (aa == 1u) {
+        u_pixel = 0.0f + rf0;        // (0 + rf) / 1 == 0 + rf exactly
+        v_pixel = 0.0f + rf1;
+    } else {
+        const uint32_t sub_row = samp / aa;
+        const uint32_t sub_col = samp - sub_row * aa;
+        u_pixel = ((float)sub_row + rf0) / (float)aa;
+        v_pixel = ((float)sub_col + rf1) / (float)aa;
+    }
     const float u = ((float)gcol + u_pixel) / (float)P->width;
     const float v = 1.0f - ((float)grow + v_pixel) / (float)P->height;
     const float dist = F->cam_distance, aspect = F->cam_aspect;
