@@ -281,7 +281,14 @@ struct NodeOut {
 #ifndef RT_SCAN_GROUP
 #define RT_SCAN_GROUP 2
 #endif
-template <bool AFFINE, bool STACK_LDS, bool SCENE_LDS, bool TEAMS>
+// FAST: the throughput variant (image render, path tracer, one pass without a round budget, one lane per
+// pixel, no diagnostics): these launch parameters fold to constants, so their registers and branches go.
+#define K_ALGO (FAST ? (uint32_t)RT_ALGO_PATHTRACER : P.algorithm)
+#define K_MODE (FAST ? 0u : P.mode)
+#define K_BUDGET (FAST ? 0u : P.budget)
+#define K_PASS (FAST ? 0u : P.pass)
+#define K_DEBUG (FAST ? (unsigned long long*)nullptr : P.debug_waves)
+template <bool AFFINE, bool STACK_LDS, bool SCENE_LDS, bool TEAMS, bool FAST>
 __global__ __launch_bounds__(RT_BLOCK, RT_WAVES_PER_EU) void k_pass(const PassParams P, const DScan* __restrict__ g_scan,
                                                    const DMRows* __restrict__ g_mrows,
                                                    const DWRows* __restrict__ g_wrows,
@@ -296,8 +303,8 @@ __global__ __launch_bounds__(RT_BLOCK, RT_WAVES_PER_EU) void k_pass(const PassPa
     // ---- this pass's input and team size (wave-uniform, the same in every wave) ----
     ColdParams C0 = cold_params();
     uint32_t n_in = C0->n_in0;
-    if (P.pass != 0u) {
-        n_in = P.ctl->count[P.pass];
+    if (K_PASS != 0u) {
+        n_in = P.ctl->count[K_PASS];
         if (n_in > C0->q_capacity) n_in = C0->q_capacity;
     }
     n_in = (uint32_t)__builtin_amdgcn_readfirstlane((int)n_in);
@@ -311,6 +318,7 @@ __global__ __launch_bounds__(RT_BLOCK, RT_WAVES_PER_EU) void k_pass(const PassPa
     // the team variant of the kernel also runs T == 1 (later passes, whose queue length only the
     // device knows); the single variant is launched for passes the host pins to one lane per pixel
     if (!TEAMS) T = 1u;
+    static_assert(!FAST || !TEAMS, "the FAST variant is one lane per pixel");
     if ((uint64_t)blockIdx.x * (RT_BLOCK / T) * C0->backlog >= (uint64_t)n_in && blockIdx.x != 0u) return;   // more blocks than work
 
     // ---- LDS: [team tables][DScan x n][DMRows x n][DShade x n][DMaterial x n (one per shape)][recursion stack] ----
@@ -380,6 +388,7 @@ __global__ __launch_bounds__(RT_BLOCK, RT_WAVES_PER_EU) void k_pass(const PassPa
     Vec3 cv = {0.f, 0.f, 1.f};           // diffuse: hit.normal (raw); specular: the mirrored direction
     // counters (kept by the team leader)
     uint32_t n_rays = 0, n_samples = 0, n_diffuse = 0, n_specular = 0;
+    uint32_t u_rays = 0, u_samples = 0, u_diffuse = 0, u_specular = 0;   // FAST: the same, wave-uniform (ballot counts)
 
     // wave-private slice of the input queue
     uint32_t wcur = 0, wend = 0;
@@ -389,12 +398,12 @@ __global__ __launch_bounds__(RT_BLOCK, RT_WAVES_PER_EU) void k_pass(const PassPa
     // diagnostics
     unsigned long long dbg_t0 = 0;
     uint32_t dbg_rounds = 0, dbg_lanes = 0;
-    if (P.debug_waves) dbg_t0 = __builtin_amdgcn_s_memrealtime();
+    if (K_DEBUG) dbg_t0 = __builtin_amdgcn_s_memrealtime();
     // section cycle counters (diagnostics): 0 generate 1 scatter 2 scan 3 hit+shade 4 resolve 5 park
     uint32_t dbg_sec0 = 0, dbg_sec1 = 0, dbg_sec2 = 0, dbg_sec3 = 0, dbg_sec4 = 0, dbg_sec5 = 0;
     uint64_t dbg_prev = 0;
 #ifdef RT_DEBUG_SECTIONS   // per-section cycle counters cost ~10 VGPRs: diagnostics builds only (make EXTRA=-DRT_DEBUG_SECTIONS)
-#define RT_DBG_MARK(i) do { if (P.debug_waves) { const uint64_t now_ = __builtin_readcyclecounter(); dbg_sec##i += (uint32_t)(now_ - dbg_prev); dbg_prev = now_; } } while (0)
+#define RT_DBG_MARK(i) do { if (K_DEBUG) { const uint64_t now_ = __builtin_readcyclecounter(); dbg_sec##i += (uint32_t)(now_ - dbg_prev); dbg_prev = now_; } } while (0)
 #else
 #define RT_DBG_MARK(i) do { (void)dbg_prev; } while (0)
 #endif
@@ -406,11 +415,11 @@ __global__ __launch_bounds__(RT_BLOCK, RT_WAVES_PER_EU) void k_pass(const PassPa
                           uint64_t& st, NodeOut& R) {
         R.leaf = true; R.traced = false; R.consumed = 0u;
         R.vr = 0.f; R.vg = 0.f; R.vb = 0.f;
-        if (P.algorithm == RT_ALGO_DUMMY) {
+        if (K_ALGO == RT_ALGO_DUMMY) {
             R.vr = 1.0f; R.vg = 2.0f; R.vb = 3.0f;   // render.rs:180-185
             return;
         }
-        if (P.algorithm == RT_ALGO_PATHTRACER && depth > P.max_depth) return;   // render.rs:137-139
+        if (K_ALGO == RT_ALGO_PATHTRACER && depth > P.max_depth) return;   // render.rs:137-139
         float t;
         Vec3 lo, ld;                 // the winner's object-space ray
         uint32_t bkind;
@@ -421,7 +430,7 @@ __global__ __launch_bounds__(RT_BLOCK, RT_WAVES_PER_EU) void k_pass(const PassPa
             R.vr = P.bg[0]; R.vg = P.bg[1]; R.vb = P.bg[2];
             return;
         }
-        if (P.algorithm == RT_ALGO_ONOFF) {
+        if (K_ALGO == RT_ALGO_ONOFF) {
             R.vr = P.fg[0]; R.vg = P.fg[1]; R.vb = P.fg[2];   // render.rs:61-66
             return;
         }
@@ -431,7 +440,7 @@ __global__ __launch_bounds__(RT_BLOCK, RT_WAVES_PER_EU) void k_pass(const PassPa
         Vec3 hc = {sh0.x, sh0.y, sh0.z};
         Vec3 em = {sh1.x, sh1.y, sh1.z};
         const uint32_t sflags = __float_as_uint(sh0.w);
-        const bool can_open = (P.algorithm == RT_ALGO_PATHTRACER) && (depth + 1u <= P.max_depth);
+        const bool can_open = (K_ALGO == RT_ALGO_PATHTRACER) && (depth + 1u <= P.max_depth);
         const float hx = lo.x + ld.x * t, hy = lo.y + ld.y * t, hz = lo.z + ld.z * t;   // inv_ray.at(t)
         const bool sphere = (bkind == RT_SHAPE_SPHERE);
         if (sflags & 6u) {
@@ -449,7 +458,7 @@ __global__ __launch_bounds__(RT_BLOCK, RT_WAVES_PER_EU) void k_pass(const PassPa
             if (sflags & 2u) hc = pigment_color(&M->brdf_pigment, texels, u, v);
             if (sflags & 4u) em = pigment_color(&M->emitted, texels, u, v);
         }
-        if (P.algorithm == RT_ALGO_FLAT) {
+        if (K_ALGO == RT_ALGO_FLAT) {
             R.vr = em.x + hc.x; R.vg = em.y + hc.y; R.vb = em.z + hc.z;   // render.rs:83-84
             return;
         }
@@ -520,7 +529,7 @@ __global__ __launch_bounds__(RT_BLOCK, RT_WAVES_PER_EU) void k_pass(const PassPa
     uint32_t idle_min = n_teams / cold_params()->idle_div;
     if (idle_min < 1u) idle_min = 1u;
 
-    if (P.debug_waves) dbg_prev = __builtin_readcyclecounter();
+    if (K_DEBUG) dbg_prev = __builtin_readcyclecounter();
     for (;;) {
         // =====================================================================================
         // generate / compact in: teams without a solve in flight retire their pixel, take the
@@ -535,7 +544,7 @@ __global__ __launch_bounds__(RT_BLOCK, RT_WAVES_PER_EU) void k_pass(const PassPa
                 if (q != RT_INVALID && samp == aa2) {
                     // pixel (or solve item) finished: color * (1 / aa^2)  (imagetracer.rs:121)
                     if (leader) {
-                        if (P.mode == 0u) {
+                        if (K_MODE == 0u) {
                             uint32_t fr, lq, gr_, gc_;
                             local_to_global(C, q, fr, lq, gr_, gc_);
                             float* o = frame_entry(C, fr)->out + 3ull * lq;
@@ -562,12 +571,12 @@ __global__ __launch_bounds__(RT_BLOCK, RT_WAVES_PER_EU) void k_pass(const PassPa
             while (wantmask != 0ull) {
                 if (wcur == wend) {
                     uint32_t b = 0;
-                    if (lane == 0) b = atomicAdd(&P.ctl->head[P.pass], n_teams);
+                    if (lane == 0) b = atomicAdd(&P.ctl->head[K_PASS], n_teams);
                     b = __shfl(b, 0);
                     if (b >= n_in) { exhausted = true; break; }
                     wcur = b;
                     wend = (b + n_teams < n_in) ? b + n_teams : n_in;
-                    if (P.pass == 0u && P.mode == 0u) {
+                    if (K_PASS == 0u && K_MODE == 0u) {
                         // master PCG at the chunk's first pixel, on the scalar unit (imagetracer.rs:63-81)
                         wbase_h = b;
                         wbase_q = (uint32_t)__builtin_amdgcn_readfirstlane((int)perm_entry(b, C->perm_stride));
@@ -587,7 +596,7 @@ __global__ __launch_bounds__(RT_BLOCK, RT_WAVES_PER_EU) void k_pass(const PassPa
                 if (lead_want && rank < cnt) {
                     h = wcur + rank;
                     // pass 0: the chunk's entries are consecutive pixels starting at wbase_q
-                    if (P.pass == 0u && P.mode == 0u) {
+                    if (K_PASS == 0u && K_MODE == 0u) {
                         h = wbase_q + (h - wbase_h);
                         my_base_p = wbase_p;
                         my_base_f = wbase_f;
@@ -607,13 +616,13 @@ __global__ __launch_bounds__(RT_BLOCK, RT_WAVES_PER_EU) void k_pass(const PassPa
             }
             if (h == RT_INVALID - 1u) h = RT_INVALID;
             if (!busy && h != RT_INVALID) {
-                rounds_left = P.budget;
-                if (P.pass == 0u) {
+                rounds_left = K_BUDGET;
+                if (K_PASS == 0u) {
                     q = h;
                     samp = 0;
                     acc_r = 0.f; acc_g = 0.f; acc_b = 0.f;
                     lvl = 0;
-                    if (P.mode == 0u) {
+                    if (K_MODE == 0u) {
                         uint32_t fr, lq, grow, gcol;
                         local_to_global(C, q, fr, lq, grow, gcol);
                         // master PCG at this pixel: jump ahead p*(2*aa^2+1) draws (imagetracer.rs:63-81),
@@ -630,7 +639,7 @@ __global__ __launch_bounds__(RT_BLOCK, RT_WAVES_PER_EU) void k_pass(const PassPa
                 } else {
                     // a path parked by the previous pass
                     const uint32_t qcap = C->q_capacity;
-                    const float* e = C->qbuf[(P.pass + 1u) & 1u] + h;
+                    const float* e = C->qbuf[(K_PASS + 1u) & 1u] + h;
                     q = __float_as_uint(e[0ull * qcap]);
                     samp = __float_as_uint(e[1ull * qcap]);
                     lvl = __float_as_uint(e[2ull * qcap]);
@@ -656,10 +665,11 @@ __global__ __launch_bounds__(RT_BLOCK, RT_WAVES_PER_EU) void k_pass(const PassPa
                     }
                 }
             }
+            if (FAST) u_samples += (uint32_t)__popcll(__ballot(!busy && q != RT_INVALID));
             if (!busy && q != RT_INVALID) {
                 // start the next top-level solve of q (imagetracer.rs:118-120); its level-0 ray is
                 // produced in the candidate stage below
-                if (P.mode == 0u) {
+                if (K_MODE == 0u) {
                     base_depth = 0;
                 } else {
                     base_depth = C->in_rays[q].depth;
@@ -667,7 +677,7 @@ __global__ __launch_bounds__(RT_BLOCK, RT_WAVES_PER_EU) void k_pass(const PassPa
                     pinc = C->io_pcgs[q].inc;
                 }
                 samp += 1;
-                if (leader) n_samples += 1;
+                if (!FAST && leader) n_samples += 1;
                 lvl = 0;
                 busy = true;
             }
@@ -681,7 +691,7 @@ __global__ __launch_bounds__(RT_BLOCK, RT_WAVES_PER_EU) void k_pass(const PassPa
         // =====================================================================================
         // this round's candidate rays: the level-0 ray, or siblings of the open hit
         // =====================================================================================
-        const uint32_t depth = base_depth + lvl;     // Ray.depth of the rays traced this round
+        const uint32_t depth = FAST ? lvl : base_depth + lvl;     // Ray.depth of the rays traced this round
         // draws an earlier sibling is assumed to consume after its two scatter draws
         const uint32_t pred = (lvl > 0u && depth >= P.rr_limit) ? 1u : 0u;
         const bool last_level = TEAMS && (lvl > 0u) && (depth == P.max_depth);
@@ -696,7 +706,7 @@ __global__ __launch_bounds__(RT_BLOCK, RT_WAVES_PER_EU) void k_pass(const PassPa
         uint32_t n_rem = 0;          // rays this level still has to start
         if (busy) n_rem = (lvl == 0u) ? 1u : (n_children - kcount);
         const bool act = busy && ((lvl == 0u) ? (jj == 0u) : (cand_ok && cj < n_rem));
-        if (P.debug_waves) { dbg_rounds += 1u; dbg_lanes += (uint32_t)__popcll(__ballot(act)); }
+        if (K_DEBUG) { dbg_rounds += 1u; dbg_lanes += (uint32_t)__popcll(__ballot(act)); }
 
         uint64_t st = pstate;        // this lane's PCG, advanced through its own ray's draws
         NodeOut R;
@@ -709,7 +719,7 @@ __global__ __launch_bounds__(RT_BLOCK, RT_WAVES_PER_EU) void k_pass(const PassPa
         if (busy && lvl == 0u) {
             // the level-0 ray of sample samp-1 (every lane of the team: the master PCG stays replicated)
             ColdParams C = cold_params();
-            if (P.mode == 0u) {
+            if (K_MODE == 0u) {
                 uint32_t fr, lq, grow, gcol;
                 local_to_global(C, q, fr, lq, grow, gcol);
                 primary_ray<AFFINE>(C, frame_entry(C, fr), grow, gcol, samp - 1u, mstate, o, d);
@@ -804,11 +814,16 @@ __global__ __launch_bounds__(RT_BLOCK, RT_WAVES_PER_EU) void k_pass(const PassPa
         } else {
             if (R.leaf) { tr = tr + pr; tg = tg + pg; tb_ = tb_ + pb; }
         }
+        if (FAST) {
+            u_rays += (uint32_t)__popcll(__ballot(busy && R.traced));
+            u_diffuse += (uint32_t)__popcll(__ballot(busy && lvl > 0u && cur_brdf == RT_BRDF_DIFFUSE));
+            u_specular += (uint32_t)__popcll(__ballot(busy && lvl > 0u && cur_brdf != RT_BRDF_DIFFUSE));
+        }
         if (busy) {
             pstate = nstate;
             if (lvl == 0u) { acc_r = tr; acc_g = tg; acc_b = tb_; }
             else { cu_r = tr; cu_g = tg; cu_b = tb_; }
-            if (leader) {
+            if (!FAST && leader) {
                 n_rays += traced_valid;
                 if (lvl > 0u) {
                     if (cur_brdf == RT_BRDF_DIFFUSE) n_diffuse += n_valid; else n_specular += n_valid;
@@ -867,17 +882,17 @@ __global__ __launch_bounds__(RT_BLOCK, RT_WAVES_PER_EU) void k_pass(const PassPa
         // =====================================================================================
         // compact out: paths that used up this pass's budget are parked for the next pass
         // =====================================================================================
-        if (P.budget != 0u) {
+        if (K_BUDGET != 0u) {
             const bool live = busy || (q != RT_INVALID && samp < aa2);
             const bool park = live && rounds_left == 0u;
             const unsigned long long pm = __ballot(park && leader);
             if (pm != 0ull) {
                 ColdParams C = cold_params();
                 const uint32_t qcap = C->q_capacity;
-                float* q_out = C->qbuf[P.pass & 1u];
+                float* q_out = C->qbuf[K_PASS & 1u];
                 uint32_t base = 0;
                 const uint32_t first = (uint32_t)__builtin_ctzll(pm);
-                if (lane == first) base = atomicAdd(&P.ctl->count[P.pass + 1u], (uint32_t)__popcll(pm));
+                if (lane == first) base = atomicAdd(&P.ctl->count[K_PASS + 1u], (uint32_t)__popcll(pm));
                 base = __shfl(base, first);
                 uint32_t slot = base + __builtin_amdgcn_mbcnt_hi((uint32_t)(pm >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)pm, 0u));
                 if (TEAMS) slot = __shfl(slot, team0);
@@ -910,7 +925,7 @@ __global__ __launch_bounds__(RT_BLOCK, RT_WAVES_PER_EU) void k_pass(const PassPa
                         q = RT_INVALID;
                         busy = false;
                     } else {
-                        rounds_left = P.budget;   // the queue is full: keep running this path here
+                        rounds_left = K_BUDGET;   // the queue is full: keep running this path here
                     }
                 }
             }
@@ -919,8 +934,8 @@ __global__ __launch_bounds__(RT_BLOCK, RT_WAVES_PER_EU) void k_pass(const PassPa
     }
     }   // round loop
 
-    if (P.debug_waves && lane == 0) {
-        unsigned long long* d = P.debug_waves + 11ull * ((unsigned long long)P.pass * P.debug_stride + (gtid >> 6));
+    if (K_DEBUG && lane == 0) {
+        unsigned long long* d = K_DEBUG + 11ull * ((unsigned long long)K_PASS * P.debug_stride + (gtid >> 6));
         d[0] = dbg_t0; d[1] = __builtin_amdgcn_s_memrealtime(); d[2] = dbg_rounds; d[3] = dbg_lanes; d[4] = T;
         d[5] = dbg_sec0; d[6] = dbg_sec1; d[7] = dbg_sec2; d[8] = dbg_sec3; d[9] = dbg_sec4; d[10] = dbg_sec5;
     }
@@ -931,9 +946,24 @@ __global__ __launch_bounds__(RT_BLOCK, RT_WAVES_PER_EU) void k_pass(const PassPa
             for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off);
             if (lane == 0 && v != 0u) atomicAdd(&P.ctl->counters[j], (unsigned long long)v);
         };
-        flush(n_rays, 0); flush(n_samples, 1); flush(n_diffuse, 2); flush(n_specular, 3);
+        if (FAST) {
+            if (lane == 0) {
+                if (u_rays) atomicAdd(&P.ctl->counters[0], (unsigned long long)u_rays);
+                if (u_samples) atomicAdd(&P.ctl->counters[1], (unsigned long long)u_samples);
+                if (u_diffuse) atomicAdd(&P.ctl->counters[2], (unsigned long long)u_diffuse);
+                if (u_specular) atomicAdd(&P.ctl->counters[3], (unsigned long long)u_specular);
+            }
+        } else {
+            flush(n_rays, 0); flush(n_samples, 1); flush(n_diffuse, 2); flush(n_specular, 3);
+        }
     }
 }
+
+#undef K_ALGO
+#undef K_MODE
+#undef K_BUDGET
+#undef K_PASS
+#undef K_DEBUG
 
 // World::ray_intersection for a batch of rays, full HitRecord (src/world.rs:32-50).
 template <bool AFFINE>
