@@ -141,13 +141,16 @@ __device__ __forceinline__ const FrameEntry* frame_entry(ColdParams C, uint32_t 
     return reinterpret_cast<const FrameEntry*>(reinterpret_cast<uintptr_t>(&C->frames_inline[0])) + frame;
 }
 
-// Saved level state accessors: STACK_LDS ? LDS : global.
+// Saved recursion levels: slot s of a lane is four float4 quads at [(s * 4 + quad) * stride] from the lane's base
+// (LDS: stride = block size, lanes 16 B apart: conflict-free 128-bit accesses; global: stride = total threads).
 template <bool STACK_LDS>
 struct LevelStack {
-    float* base;       // LDS: &lds[tid]; global: &gstack[gtid]
+    float4* base;      // LDS: &lds[tid]; global: &gstack[gtid]
     uint32_t stride;   // blockDim or total threads
-    __device__ __forceinline__ void st(uint32_t slot, uint32_t f, float v) const { base[(slot * RT_NF + f) * stride] = v; }
-    __device__ __forceinline__ float ld(uint32_t slot, uint32_t f) const { return base[(slot * RT_NF + f) * stride]; }
+    __device__ __forceinline__ void st4(uint32_t slot, uint32_t quad, float4 v) const { base[(slot * (RT_NF / 4) + quad) * stride] = v; }
+    __device__ __forceinline__ float4 ld4(uint32_t slot, uint32_t quad) const { return base[(slot * (RT_NF / 4) + quad) * stride]; }
+    // dword i = slot * RT_NF + field (the order in which a parked path stores its saved levels)
+    __device__ __forceinline__ float& dword(uint32_t i) const { return reinterpret_cast<float*>(base + (i >> 2) * stride)[i & 3u]; }
 };
 
 // Master PCG of ImageTracer::all_rays at global pixel p: Pcg::new(init_state, init_seq) advanced by
@@ -287,7 +290,11 @@ struct NodeOut {
 #define K_MODE (FAST ? 0u : P.mode)
 #define K_BUDGET (FAST ? 0u : P.budget)
 #define K_PASS (FAST ? 0u : P.pass)
+#ifdef RT_DEBUG_SECTIONS
+#define K_DEBUG (P.debug_waves)
+#else
 #define K_DEBUG (FAST ? (unsigned long long*)nullptr : P.debug_waves)
+#endif
 template <bool AFFINE, bool STACK_LDS, bool SCENE_LDS, bool TEAMS, bool FAST>
 __global__ __launch_bounds__(RT_BLOCK, RT_WAVES_PER_EU) void k_pass(const PassParams P, const DScan* __restrict__ g_scan,
                                                    const DMRows* __restrict__ g_mrows,
@@ -328,7 +335,7 @@ __global__ __launch_bounds__(RT_BLOCK, RT_WAVES_PER_EU) void k_pass(const PassPa
     DMRows* lds_mrows = reinterpret_cast<DMRows*>(lds_scan + n_staged);
     DShade* lds_shade = reinterpret_cast<DShade*>(lds_mrows + n_staged);
     DMaterial* lds_mats = reinterpret_cast<DMaterial*>(lds_shade + n_staged);
-    float* lds_stack = reinterpret_cast<float*>(lds_mats + n_staged);
+    float4* lds_stack = reinterpret_cast<float4*>(lds_mats + n_staged);
     if (TEAMS) {
         const uint32_t* src = reinterpret_cast<const uint32_t*>(C0->tables);
         uint32_t* dst = reinterpret_cast<uint32_t*>(lds_tab);
@@ -363,7 +370,7 @@ __global__ __launch_bounds__(RT_BLOCK, RT_WAVES_PER_EU) void k_pass(const PassPa
 
     LevelStack<STACK_LDS> stack;
     if (STACK_LDS) { stack.base = lds_stack + tid; stack.stride = RT_BLOCK; }
-    else { stack.base = C0->gstack + gtid; stack.stride = C0->total_threads; }
+    else { stack.base = reinterpret_cast<float4*>(C0->gstack) + gtid; stack.stride = C0->total_threads; }
 
     const uint32_t aa2 = C0->aa * C0->aa;
     const uint32_t n_children = P.num_of_rays;
@@ -401,6 +408,8 @@ __global__ __launch_bounds__(RT_BLOCK, RT_WAVES_PER_EU) void k_pass(const PassPa
     if (K_DEBUG) dbg_t0 = __builtin_amdgcn_s_memrealtime();
     // section cycle counters (diagnostics): 0 generate 1 scatter 2 scan 3 hit+shade 4 resolve 5 park
     uint32_t dbg_sec0 = 0, dbg_sec1 = 0, dbg_sec2 = 0, dbg_sec3 = 0, dbg_sec4 = 0, dbg_sec5 = 0;
+    // finer marks: 6 hit point + pigments 7 roulette 8 leaf value / draw skip 9 open hit 10 push 11 pop
+    uint32_t dbg_sec6 = 0, dbg_sec7 = 0, dbg_sec8 = 0, dbg_sec9 = 0, dbg_sec10 = 0, dbg_sec11 = 0;
     uint64_t dbg_prev = 0;
 #ifdef RT_DEBUG_SECTIONS   // per-section cycle counters cost ~10 VGPRs: diagnostics builds only (make EXTRA=-DRT_DEBUG_SECTIONS)
 #define RT_DBG_MARK(i) do { if (K_DEBUG) { const uint64_t now_ = __builtin_readcyclecounter(); dbg_sec##i += (uint32_t)(now_ - dbg_prev); dbg_prev = now_; } } while (0)
@@ -458,6 +467,7 @@ __global__ __launch_bounds__(RT_BLOCK, RT_WAVES_PER_EU) void k_pass(const PassPa
             if (sflags & 2u) hc = pigment_color(&M->brdf_pigment, texels, u, v);
             if (sflags & 4u) em = pigment_color(&M->emitted, texels, u, v);
         }
+        RT_DBG_MARK(6);
         if (K_ALGO == RT_ALGO_FLAT) {
             R.vr = em.x + hc.x; R.vg = em.y + hc.y; R.vb = em.z + hc.z;   // render.rs:83-84
             return;
@@ -475,6 +485,7 @@ __global__ __launch_bounds__(RT_BLOCK, RT_WAVES_PER_EU) void k_pass(const PassPa
                 return;
             }
         }
+        RT_DBG_MARK(7);
         if (lum > 0.0f && n_children != 0u) {
             if (!can_open) {
                 // every child returns black without an intersection (render.rs:137-139) but its
@@ -485,6 +496,7 @@ __global__ __launch_bounds__(RT_BLOCK, RT_WAVES_PER_EU) void k_pass(const PassPa
                 R.vr = em.x + cr * P.inv_num_of_rays;
                 R.vg = em.y + cg * P.inv_num_of_rays;
                 R.vb = em.z + cb * P.inv_num_of_rays;
+                RT_DBG_MARK(8);
             } else {
                 R.leaf = false;
                 R.ihc = hc; R.iem = em;
@@ -507,6 +519,7 @@ __global__ __launch_bounds__(RT_BLOCK, RT_WAVES_PER_EU) void k_pass(const PassPa
                 // direction, computed once from hit.ray.dir and hit.normal (material.rs:225-246)
                 if (R.ibrdf == RT_BRDF_SPECULAR) R.icv = specular_scatter_dir(d, nrm);
                 else R.icv = nrm;
+                RT_DBG_MARK(9);
             }
         } else {
             // no children: emitted + 0 * (1/n) (render.rs:157, :171)
@@ -660,7 +673,7 @@ __global__ __launch_bounds__(RT_BLOCK, RT_WAVES_PER_EU) void k_pass(const PassPa
                         cur_brdf = kb & 1u;
                         const uint32_t n_saved = (lvl - 1u) * RT_NF;
                         const float* sv = c + (uint64_t)RT_NF * qcap;
-                        for (uint32_t i = 0; i < n_saved; ++i) stack.base[i * stack.stride] = sv[(uint64_t)i * qcap];
+                        for (uint32_t i = 0; i < n_saved; ++i) stack.dword(i) = sv[(uint64_t)i * qcap];
                         busy = true;
                     }
                 }
@@ -831,17 +844,16 @@ __global__ __launch_bounds__(RT_BLOCK, RT_WAVES_PER_EU) void k_pass(const PassPa
             }
             if (lvl > 0u) kcount += n_valid;
             if (rounds_left > 0u) rounds_left -= 1u;
+            RT_DBG_MARK(4);
 
             if (!last_leaf) {
                 // the last kept sibling is an open hit: it becomes the current level
                 if (lvl > 0u) {
                     const uint32_t s = lvl - 1u;
-                    stack.st(s, 0, hc_r); stack.st(s, 1, hc_g); stack.st(s, 2, hc_b);
-                    stack.st(s, 3, em_r); stack.st(s, 4, em_g); stack.st(s, 5, em_b);
-                    stack.st(s, 6, cu_r); stack.st(s, 7, cu_g); stack.st(s, 8, cu_b);
-                    stack.st(s, 9, cw.x); stack.st(s, 10, cw.y); stack.st(s, 11, cw.z);
-                    stack.st(s, 12, cv.x); stack.st(s, 13, cv.y); stack.st(s, 14, cv.z);
-                    stack.st(s, 15, __uint_as_float((kcount << 1) | cur_brdf));
+                    stack.st4(s, 0, make_float4(hc_r, hc_g, hc_b, em_r));
+                    stack.st4(s, 1, make_float4(em_g, em_b, cu_r, cu_g));
+                    stack.st4(s, 2, make_float4(cu_b, cw.x, cw.y, cw.z));
+                    stack.st4(s, 3, make_float4(cv.x, cv.y, cv.z, __uint_as_float((kcount << 1) | cur_brdf)));
                 }
                 hc_r = R.ihc.x; hc_g = R.ihc.y; hc_b = R.ihc.z;
                 em_r = R.iem.x; em_g = R.iem.y; em_b = R.iem.z;
@@ -850,6 +862,7 @@ __global__ __launch_bounds__(RT_BLOCK, RT_WAVES_PER_EU) void k_pass(const PassPa
                 cu_r = 0.f; cu_g = 0.f; cu_b = 0.f;
                 kcount = 0;
                 lvl += 1u;
+                RT_DBG_MARK(10);
             } else if (lvl == 0u) {
                 busy = false;      // the level-0 ray returned: this solve is done
             } else {
@@ -865,16 +878,18 @@ __global__ __launch_bounds__(RT_BLOCK, RT_WAVES_PER_EU) void k_pass(const PassPa
                         break;
                     }
                     const uint32_t s = lvl - 1u;
-                    hc_r = stack.ld(s, 0); hc_g = stack.ld(s, 1); hc_b = stack.ld(s, 2);
-                    em_r = stack.ld(s, 3); em_g = stack.ld(s, 4); em_b = stack.ld(s, 5);
-                    cu_r = stack.ld(s, 6); cu_g = stack.ld(s, 7); cu_b = stack.ld(s, 8);
-                    cw.x = stack.ld(s, 9); cw.y = stack.ld(s, 10); cw.z = stack.ld(s, 11);
-                    cv.x = stack.ld(s, 12); cv.y = stack.ld(s, 13); cv.z = stack.ld(s, 14);
-                    const uint32_t kb = __float_as_uint(stack.ld(s, 15));
+                    const float4 s0 = stack.ld4(s, 0), s1 = stack.ld4(s, 1), s2 = stack.ld4(s, 2), s3 = stack.ld4(s, 3);
+                    hc_r = s0.x; hc_g = s0.y; hc_b = s0.z;
+                    em_r = s0.w; em_g = s1.x; em_b = s1.y;
+                    cu_r = s1.z; cu_g = s1.w; cu_b = s2.x;
+                    cw.x = s2.y; cw.y = s2.z; cw.z = s2.w;
+                    cv.x = s3.x; cv.y = s3.y; cv.z = s3.z;
+                    const uint32_t kb = __float_as_uint(s3.w);
                     kcount = kb >> 1;
                     cur_brdf = kb & 1u;
                     cu_r = cu_r + hc_r * wr; cu_g = cu_g + hc_g * wg; cu_b = cu_b + hc_b * wb;   // render.rs:168
                 }
+                RT_DBG_MARK(11);
             }
         }
 
@@ -919,7 +934,7 @@ __global__ __launch_bounds__(RT_BLOCK, RT_WAVES_PER_EU) void k_pass(const PassPa
                                 c[15ull * qcap] = __uint_as_float((kcount << 1) | cur_brdf);
                                 const uint32_t n_saved = (plvl - 1u) * RT_NF;
                                 float* sv = c + (uint64_t)RT_NF * qcap;
-                                for (uint32_t i = 0; i < n_saved; ++i) sv[(uint64_t)i * qcap] = stack.base[i * stack.stride];
+                                for (uint32_t i = 0; i < n_saved; ++i) sv[(uint64_t)i * qcap] = stack.dword(i);
                             }
                         }
                         q = RT_INVALID;
@@ -935,9 +950,10 @@ __global__ __launch_bounds__(RT_BLOCK, RT_WAVES_PER_EU) void k_pass(const PassPa
     }   // round loop
 
     if (K_DEBUG && lane == 0) {
-        unsigned long long* d = K_DEBUG + 11ull * ((unsigned long long)K_PASS * P.debug_stride + (gtid >> 6));
+        unsigned long long* d = K_DEBUG + 17ull * ((unsigned long long)K_PASS * P.debug_stride + (gtid >> 6));
         d[0] = dbg_t0; d[1] = __builtin_amdgcn_s_memrealtime(); d[2] = dbg_rounds; d[3] = dbg_lanes; d[4] = T;
         d[5] = dbg_sec0; d[6] = dbg_sec1; d[7] = dbg_sec2; d[8] = dbg_sec3; d[9] = dbg_sec4; d[10] = dbg_sec5;
+        d[11] = dbg_sec6; d[12] = dbg_sec7; d[13] = dbg_sec8; d[14] = dbg_sec9; d[15] = dbg_sec10; d[16] = dbg_sec11;
     }
     // ---- counters: wave reduction, one atomic per wave and counter ----
     {

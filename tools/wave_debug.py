@@ -24,7 +24,7 @@ for rep in range(3):
     _abi.check(lib.rt_render_frames(dev.handle, cams, NF, C.byref(rr), W, H, 42, 54, AA, None, outs, None, C.byref(st)))
 raw = np.fromfile(path, dtype=np.uint64)
 n_pass, n_waves = int(raw[0]), int(raw[1])
-d = raw[2:].reshape(n_pass, n_waves, 11).astype(np.float64)
+d = raw[2:].reshape(n_pass, n_waves, 17).astype(np.float64)
 print(f"kernel_ms={st.kernel_ms:.3f} rays={st.rays} passes={n_pass}")
 T0 = d[0, :, 0][d[0, :, 0] > 0].min()
 tot_rounds = 0
@@ -41,5 +41,5 @@ for p in range(n_pass):
     print(f"pass {p}: T={int(team.max())} waves {m.sum()} start {(t0.min()-T0)/100:.0f} us end {(t1.max()-T0)/100:.0f} us | "
           f"life mean {life.mean():.0f} p90 {np.percentile(life,90):.0f} max {life.max():.0f} us | rounds mean {rounds.mean():.0f} max {rounds.max():.0f} "
           f"| wave-rounds {rounds.sum():.3e} lanes/round {lanes.sum()/max(rounds.sum(),1):.1f} | us/round {(life.sum()/max(rounds.sum(),1)):.2f}")
-    print("        cycles/round: generate %.0f scatter %.0f scan %.0f hit+shade %.0f resolve %.0f park %.0f" % tuple(sec))
+    print("        cycles/round: generate %.0f scatter %.0f scan %.0f shade-rest %.0f fold %.0f park/rest %.0f | hit+pigment %.0f roulette %.0f leaf/skip %.0f open %.0f push %.0f pop %.0f  (total %.0f)" % (tuple(sec) + (sec.sum(),)))
 print(f"total wave-rounds {tot_rounds:.3e}")
