@@ -29,6 +29,17 @@
 #define RT_HD static inline
 #endif
 
+/* Binary64 literals of the polynomial kernels.  On the device each one is pinned to a scalar register
+ * pair at its use (s_mov_b32 x2 on the scalar unit, then the SGPR operand of v_fma_f64): left alone,
+ * the compiler parks every literal in a VGPR pair for the whole render loop (36 VGPRs) and feeds
+ * v_fmac_f64 through a v_mov_b64 per Horner step. */
+#if defined(__HIP_DEVICE_COMPILE__)
+__device__ __forceinline__ double rt_k_sgpr(double c) { asm volatile("" : "+s"(c)); return c; }
+#define RT_K(x) rt_k_sgpr(x)
+#else
+#define RT_K(x) (x)
+#endif
+
 /* ---- small exact helpers ------------------------------------------------------------------ */
 
 /* Rust `x as u32` for f32: saturating, NaN -> 0 (material.rs:56-57, :88-89). */
@@ -63,26 +74,26 @@ RT_HD double rt_fma_d(double a, double b, double c) { return __builtin_fma(a, b,
 
 /* sin(r) = r + r^3 * P(r^2), Taylor through r^15: truncation < 4.7e-17 on |r| <= pi/4. */
 RT_HD double rt_ksin_d(double r, double z) {
-    double p = -7.647163731819816e-13;                /* -1/15! */
-    p = rt_fma_d(p, z, 1.6059043836821613e-10);       /*  1/13! */
-    p = rt_fma_d(p, z, -2.505210838544172e-08);       /* -1/11! */
-    p = rt_fma_d(p, z, 2.7557319223985893e-06);       /*  1/9!  */
-    p = rt_fma_d(p, z, -0.0001984126984126984);       /* -1/7!  */
-    p = rt_fma_d(p, z, 0.008333333333333333);         /*  1/5!  */
-    p = rt_fma_d(p, z, -0.16666666666666666);         /* -1/3!  */
+    double p = RT_K(-7.647163731819816e-13);                /* -1/15! */
+    p = rt_fma_d(p, z, RT_K(1.6059043836821613e-10));       /*  1/13! */
+    p = rt_fma_d(p, z, RT_K(-2.505210838544172e-08));       /* -1/11! */
+    p = rt_fma_d(p, z, RT_K(2.7557319223985893e-06));       /*  1/9!  */
+    p = rt_fma_d(p, z, RT_K(-0.0001984126984126984));       /* -1/7!  */
+    p = rt_fma_d(p, z, RT_K(0.008333333333333333));         /*  1/5!  */
+    p = rt_fma_d(p, z, RT_K(-0.16666666666666666));         /* -1/3!  */
     return rt_fma_d(r * z, p, r);
 }
 
 /* cos(r) = 1 + r^2 * Q(r^2), Taylor through r^16: truncation < 2e-18 on |r| <= pi/4. */
 RT_HD double rt_kcos_d(double z) {
-    double p = 4.779477332387385e-14;                 /*  1/16! */
-    p = rt_fma_d(p, z, -1.1470745597729725e-11);      /* -1/14! */
-    p = rt_fma_d(p, z, 2.08767569878681e-09);         /*  1/12! */
-    p = rt_fma_d(p, z, -2.755731922398589e-07);       /* -1/10! */
-    p = rt_fma_d(p, z, 2.48015873015873e-05);         /*  1/8!  */
-    p = rt_fma_d(p, z, -0.001388888888888889);        /* -1/6!  */
-    p = rt_fma_d(p, z, 0.041666666666666664);         /*  1/4!  */
-    p = rt_fma_d(p, z, -0.5);                         /* -1/2!  */
+    double p = RT_K(4.779477332387385e-14);                 /*  1/16! */
+    p = rt_fma_d(p, z, RT_K(-1.1470745597729725e-11));      /* -1/14! */
+    p = rt_fma_d(p, z, RT_K(2.08767569878681e-09));         /*  1/12! */
+    p = rt_fma_d(p, z, RT_K(-2.755731922398589e-07));       /* -1/10! */
+    p = rt_fma_d(p, z, RT_K(2.48015873015873e-05));         /*  1/8!  */
+    p = rt_fma_d(p, z, RT_K(-0.001388888888888889));        /* -1/6!  */
+    p = rt_fma_d(p, z, RT_K(0.041666666666666664));         /*  1/4!  */
+    p = rt_fma_d(p, z, RT_K(-0.5));                         /* -1/2!  */
     return rt_fma_d(z, p, 1.0);
 }
 
@@ -90,10 +101,10 @@ RT_HD double rt_kcos_d(double z) {
  * commute with that rounding). */
 RT_HD void rt_sincosf(float xf, float* s, float* c) {
     const double x = (double)xf;
-    const double fn = rt_rint_d(x * RT_INV_PIO2);
-    double r = rt_fma_d(-fn, RT_PIO2_1, x);
-    r = rt_fma_d(-fn, RT_PIO2_2, r);
-    r = rt_fma_d(-fn, RT_PIO2_3, r);
+    const double fn = rt_rint_d(x * RT_K(RT_INV_PIO2));
+    double r = rt_fma_d(-fn, RT_K(RT_PIO2_1), x);
+    r = rt_fma_d(-fn, RT_K(RT_PIO2_2), r);
+    r = rt_fma_d(-fn, RT_K(RT_PIO2_3), r);
     const double z = r * r;
     const float ks = (float)rt_ksin_d(r, z);
     const float kc = (float)rt_kcos_d(z);
@@ -120,26 +131,26 @@ RT_HD double rt_atan01_d(double a) {
     double base;
     switch (i) {
         case 0: base = 0.0; break;
-        case 1: base = 0.12435499454676144; break;
-        case 2: base = 0.24497866312686414; break;
-        case 3: base = 0.35877067027057225; break;
-        case 4: base = 0.4636476090008061; break;
-        case 5: base = 0.5585993153435624; break;
-        case 6: base = 0.6435011087932844; break;
-        case 7: base = 0.7188299996216245; break;
-        default: base = 0.7853981633974483; break;
+        case 1: base = RT_K(0.12435499454676144); break;
+        case 2: base = RT_K(0.24497866312686414); break;
+        case 3: base = RT_K(0.35877067027057225); break;
+        case 4: base = RT_K(0.4636476090008061); break;
+        case 5: base = RT_K(0.5585993153435624); break;
+        case 6: base = RT_K(0.6435011087932844); break;
+        case 7: base = RT_K(0.7188299996216245); break;
+        default: base = RT_K(0.7853981633974483); break;
     }
     const double c = k * 0.125;
     const double t = (a - c) / (1.0 + a * c);
     const double z = t * t;
-    double p = 0.058823529411764705;          /*  1/17 */
-    p = p * z - 0.06666666666666667;          /* -1/15 */
-    p = p * z + 0.07692307692307693;          /*  1/13 */
-    p = p * z - 0.09090909090909091;          /* -1/11 */
-    p = p * z + 0.1111111111111111;           /*  1/9  */
-    p = p * z - 0.14285714285714285;          /* -1/7  */
-    p = p * z + 0.2;                          /*  1/5  */
-    p = p * z - 0.3333333333333333;           /* -1/3  */
+    double p = RT_K(0.058823529411764705);          /*  1/17 */
+    p = p * z - RT_K(0.06666666666666667);          /* -1/15 */
+    p = p * z + RT_K(0.07692307692307693);          /*  1/13 */
+    p = p * z - RT_K(0.09090909090909091);          /* -1/11 */
+    p = p * z + RT_K(0.1111111111111111);           /*  1/9  */
+    p = p * z - RT_K(0.14285714285714285);          /* -1/7  */
+    p = p * z + RT_K(0.2);                          /*  1/5  */
+    p = p * z - RT_K(0.3333333333333333);           /* -1/3  */
     return base + (t + (t * z) * p);
 }
 
@@ -151,13 +162,13 @@ RT_HD double rt_atan2_d(double y, double x) {
     if (ay == 0.0) {
         r = 0.0;                               /* atan2(+-0, x) */
     } else if (ax == ay) {
-        r = 0.7853981633974483;                /* includes inf/inf */
+        r = RT_K(0.7853981633974483);          /* includes inf/inf */
     } else if (ax > ay) {
         r = rt_atan01_d(ay / ax);              /* ay/inf = 0 */
     } else {
-        r = RT_PIO2_D - rt_atan01_d(ax / ay);
+        r = RT_K(RT_PIO2_D) - rt_atan01_d(ax / ay);
     }
-    if (__builtin_signbit(x)) r = RT_PI_D - r;
+    if (__builtin_signbit(x)) r = RT_K(RT_PI_D) - r;
     return __builtin_signbit(y) ? -r : r;
 }
 
