@@ -701,6 +701,184 @@ __global__ __launch_bounds__(RT_BLOCK, RT_WAVES_PER_EU) void k_pass(const PassPa
         }
         RT_DBG_MARK(0);
 
+        if constexpr (FAST) {
+            // =================================================================================
+            // FAST: one lane per pixel; intersect, shade and resolve fused.  The same draws and f32
+            // operations as the general path below (trace_node + resolve), but a hit that opens
+            // writes the recursion state directly (no NodeOut record to merge) and a leaf is folded
+            // where its value is known.
+            // =================================================================================
+            u_rays += (uint32_t)__popcll(__ballot(busy));           // every live lane traces one ray per round
+            u_diffuse += (uint32_t)__popcll(__ballot(busy && lvl > 0u && cur_brdf == RT_BRDF_DIFFUSE));
+            u_specular += (uint32_t)__popcll(__ballot(busy && lvl > 0u && cur_brdf != RT_BRDF_DIFFUSE));
+            if (busy) {
+                const uint32_t depth = lvl;                         // Ray.depth (the level-0 ray has depth 0)
+                uint64_t st = pstate;
+                Vec3 o, d;
+                float tmin;
+                if (lvl == 0u) {
+                    // the level-0 ray of sample samp-1 (imagetracer.rs:52-56, :67-75)
+                    ColdParams C = cold_params();
+                    uint32_t fr, lq, grow, gcol;
+                    local_to_global(C, q, fr, lq, grow, gcol);
+                    primary_ray<AFFINE>(C, frame_entry(C, fr), grow, gcol, samp - 1u, mstate, o, d);
+                    tmin = 1e-5f;                                   // Ray::default (ray.rs:50)
+                } else {
+                    // BRDF::scatter_ray of the next child of the open hit (render.rs:160-166)
+                    const float rf0 = pcg_random_float(st, pinc);
+                    const float rf1 = pcg_random_float(st, pinc);
+                    if (cur_brdf == RT_BRDF_DIFFUSE) {
+                        d = diffuse_scatter_dir(rf0, rf1, cv);
+                        tmin = 1.0e-3f;                             // material.rs:181
+                    } else {
+                        d = cv;
+                        tmin = 1e-5f;
+                    }
+                    o = cw;
+                }
+                RT_DBG_MARK(1);
+                float t;
+                Vec3 lo, ld;
+                uint32_t bkind;
+                const int best = scan_closest_hit_g<AFFINE, RT_SCAN_GROUP>(scan, g_wrows, P.n_shapes, o, d, tmin, __builtin_inff(), t, lo, ld, bkind);
+                RT_DBG_MARK(2);
+                bool leaf = true;
+                float vr, vg, vb;                                   // what the ray returns, when it is a leaf
+                if (best < 0) {
+                    vr = P.bg[0]; vg = P.bg[1]; vb = P.bg[2];       // render.rs:140-143
+                } else {
+                    const float4* shp = reinterpret_cast<const float4*>(shade + best);
+                    const float4 sh0 = shp[0], sh1 = shp[1];
+                    Vec3 hc = {sh0.x, sh0.y, sh0.z};
+                    Vec3 em = {sh1.x, sh1.y, sh1.z};
+                    const uint32_t sflags = __float_as_uint(sh0.w);
+                    const float hx = lo.x + ld.x * t, hy = lo.y + ld.y * t, hz = lo.z + ld.z * t;   // inv_ray.at(t)
+                    const bool sphere = (bkind == RT_SHAPE_SPHERE);
+                    if (sflags & 6u) {
+                        float u, v;
+                        if (sphere) {
+                            u = rt_atan2f(hy, hx) / 6.2831854820251465f;
+                            v = rt_acosf(hz) / 3.1415927410125732f;
+                            if (u < 0.0f) u += 1.0f;
+                        } else {
+                            u = hx - __builtin_floorf(hx);
+                            v = hy - __builtin_floorf(hy);
+                        }
+                        const DMaterial* M = mats + (SCENE_LDS ? (uint32_t)best : scan[best].material);
+                        if (sflags & 2u) hc = pigment_color(&M->brdf_pigment, texels, u, v);
+                        if (sflags & 4u) em = pigment_color(&M->emitted, texels, u, v);
+                    }
+                    RT_DBG_MARK(6);
+                    const float lum = rt_maxf(hc.x, rt_maxf(hc.y, hc.z));
+                    bool alive = true;
+                    if (depth >= P.rr_limit) {                      // render.rs:149-156
+                        const float rq = rt_maxf(1.0f - lum, 0.05f);
+                        if (pcg_random_float(st, pinc) > rq) {
+                            const float s = 1.0f / (1.0f - rq);
+                            hc.x = hc.x * s; hc.y = hc.y * s; hc.z = hc.z * s;
+                        } else {
+                            vr = em.x; vg = em.y; vb = em.z;
+                            alive = false;
+                        }
+                    }
+                    RT_DBG_MARK(7);
+                    if (alive) {
+                        if (lum > 0.0f && n_children != 0u) {
+                            if (depth + 1u > P.max_depth) {
+                                // every child returns black without an intersection (render.rs:137-139)
+                                // but its two scatter draws are consumed (render.rs:161)
+                                st = st * P.skip_mult + pinc * P.skip_plus;
+                                const float cr = 0.0f + hc.x * 0.0f, cg = 0.0f + hc.y * 0.0f, cb = 0.0f + hc.z * 0.0f;
+                                vr = em.x + cr * P.inv_num_of_rays;
+                                vg = em.y + cg * P.inv_num_of_rays;
+                                vb = em.z + cb * P.inv_num_of_rays;
+                                RT_DBG_MARK(8);
+                            } else {
+                                // the hit opens: world_point and normal (src/shape.rs:88-95, :134-138, :175-182,
+                                // :205-209), then it becomes the current level
+                                leaf = false;
+                                const Rows3 MW = load_rows(mrows[best].m);
+                                const Rows3 IW = load_rows(scan[best].inv);
+                                const Vec3 wp = rows_point<AFFINE>(MW, AFFINE ? nullptr : g_wrows[best].m_w, hx, hy, hz);
+                                float nx, ny, nz, dp;
+                                if (sphere) {
+                                    dp = hx * ld.x + hy * ld.y + hz * ld.z;
+                                    nx = hx; ny = hy; nz = hz;
+                                } else {
+                                    dp = 0.0f * ld.x + 0.0f * ld.y + 1.0f * ld.z;
+                                    nx = 0.0f; ny = 0.0f; nz = 1.0f;
+                                }
+                                if (!(dp < 0.0f)) { nx = -nx; ny = -ny; nz = -nz; }
+                                const Vec3 nrm = rows_normal(IW, nx, ny, nz);
+                                const uint32_t nbrdf = sflags & 1u;
+                                // every child of a mirror hit has the same direction (material.rs:225-246)
+                                const Vec3 ncv = (nbrdf == RT_BRDF_SPECULAR) ? specular_scatter_dir(d, nrm) : nrm;
+                                RT_DBG_MARK(9);
+                                if (lvl > 0u) {
+                                    kcount += 1u;                   // this child of the level that is saved
+                                    const uint32_t s = lvl - 1u;
+                                    stack.st4(s, 0, make_float4(hc_r, hc_g, hc_b, em_r));
+                                    stack.st4(s, 1, make_float4(em_g, em_b, cu_r, cu_g));
+                                    stack.st4(s, 2, make_float4(cu_b, cw.x, cw.y, cw.z));
+                                    stack.st4(s, 3, make_float4(cv.x, cv.y, cv.z, __uint_as_float((kcount << 1) | cur_brdf)));
+                                }
+                                hc_r = hc.x; hc_g = hc.y; hc_b = hc.z;
+                                em_r = em.x; em_g = em.y; em_b = em.z;
+                                cw = wp; cv = ncv;
+                                cur_brdf = nbrdf;
+                                cu_r = 0.f; cu_g = 0.f; cu_b = 0.f;
+                                kcount = 0;
+                                lvl += 1u;
+                                RT_DBG_MARK(10);
+                            }
+                        } else {
+                            // no children: emitted + 0 * (1/n) (render.rs:157, :171)
+                            vr = em.x + 0.0f * P.inv_num_of_rays;
+                            vg = em.y + 0.0f * P.inv_num_of_rays;
+                            vb = em.z + 0.0f * P.inv_num_of_rays;
+                        }
+                    }
+                }
+                pstate = st;
+                if (leaf) {
+                    if (lvl == 0u) {
+                        acc_r = acc_r + vr; acc_g = acc_g + vg; acc_b = acc_b + vb;   // imagetracer.rs:119
+                        busy = false;
+                    } else {
+                        cu_r = cu_r + hc_r * vr; cu_g = cu_g + hc_g * vg; cu_b = cu_b + hc_b * vb;   // render.rs:168
+                        kcount += 1u;
+                        RT_DBG_MARK(4);
+                        // levels whose children have all returned close and return to their parent
+                        while (kcount == n_children) {
+                            const float wr = em_r + cu_r * P.inv_num_of_rays;   // render.rs:171
+                            const float wg = em_g + cu_g * P.inv_num_of_rays;
+                            const float wb = em_b + cu_b * P.inv_num_of_rays;
+                            lvl -= 1u;
+                            if (lvl == 0u) {
+                                acc_r = acc_r + wr; acc_g = acc_g + wg; acc_b = acc_b + wb;   // imagetracer.rs:119
+                                busy = false;
+                                break;
+                            }
+                            const uint32_t s = lvl - 1u;
+                            const float4 s0 = stack.ld4(s, 0), s1 = stack.ld4(s, 1), s2 = stack.ld4(s, 2), s3 = stack.ld4(s, 3);
+                            hc_r = s0.x; hc_g = s0.y; hc_b = s0.z;
+                            em_r = s0.w; em_g = s1.x; em_b = s1.y;
+                            cu_r = s1.z; cu_g = s1.w; cu_b = s2.x;
+                            cw.x = s2.y; cw.y = s2.z; cw.z = s2.w;
+                            cv.x = s3.x; cv.y = s3.y; cv.z = s3.z;
+                            const uint32_t kb = __float_as_uint(s3.w);
+                            kcount = kb >> 1;
+                            cur_brdf = kb & 1u;
+                            cu_r = cu_r + hc_r * wr; cu_g = cu_g + hc_g * wg; cu_b = cu_b + hc_b * wb;   // render.rs:168
+                        }
+                        RT_DBG_MARK(11);
+                    }
+                }
+            }
+            RT_DBG_MARK(5);
+            continue;
+        }
+
         // =====================================================================================
         // this round's candidate rays: the level-0 ray, or siblings of the open hit
         // =====================================================================================
@@ -826,11 +1004,6 @@ __global__ __launch_bounds__(RT_BLOCK, RT_WAVES_PER_EU) void k_pass(const PassPa
             }
         } else {
             if (R.leaf) { tr = tr + pr; tg = tg + pg; tb_ = tb_ + pb; }
-        }
-        if (FAST) {
-            u_rays += (uint32_t)__popcll(__ballot(busy && R.traced));
-            u_diffuse += (uint32_t)__popcll(__ballot(busy && lvl > 0u && cur_brdf == RT_BRDF_DIFFUSE));
-            u_specular += (uint32_t)__popcll(__ballot(busy && lvl > 0u && cur_brdf != RT_BRDF_DIFFUSE));
         }
         if (busy) {
             pstate = nstate;
