@@ -51,9 +51,15 @@ RT_HD uint32_t rt_f32_to_u32_sat(float x) {
 
 /* Rust f32::max: if one operand is NaN the other is returned (render.rs:148, :150). */
 RT_HD float rt_maxf(float a, float b) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    /* v_max_f32: IEEE maxNum, the same value (the sign of a zero result is never observed by the
+     * renderers: lum > 0, 1 - lum and max(.., 0.05) do not depend on it) */
+    return __builtin_fmaxf(a, b);
+#else
     if (a != a) return b;
     if (b != b) return a;
     return (a > b) ? a : b;
+#endif
 }
 
 /* ---- sin / cos ---------------------------------------------------------------------------- */

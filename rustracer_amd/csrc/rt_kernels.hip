@@ -382,6 +382,7 @@ __global__ __launch_bounds__(RT_BLOCK, RT_WAVES_PER_EU) void k_pass(const PassPa
     uint32_t samp = 0;              // samples of q already started
     uint64_t mstate = 0;            // master PCG state at the next jitter draw of q
     uint64_t pstate = 0, pinc = 1;  // the pixel's PCG (state before this round's draws)
+    uint64_t pskip = 0;             // FAST: pinc * skip_plus (the increment part of skipping 2*num_of_rays draws)
     float acc_r = 0.f, acc_g = 0.f, acc_b = 0.f;
     bool busy = false;              // a top-level solve of q is in flight
     uint32_t lvl = 0;               // recursion level of the rays traced next (0 = the level-0 ray)
@@ -648,6 +649,7 @@ __global__ __launch_bounds__(RT_BLOCK, RT_WAVES_PER_EU) void k_pass(const PassPa
                         const uint64_t sq = s * C->seq_mult + C->seq_plus;
                         const uint64_t seq = (uint64_t)pcg_output(sq);
                         pcg_new(C->init_state, seq, pstate, pinc);   // imagetracer.rs:117
+                        if (FAST) pskip = pinc * P.skip_plus;
                     }
                 } else {
                     // a path parked by the previous pass
@@ -771,12 +773,11 @@ __global__ __launch_bounds__(RT_BLOCK, RT_WAVES_PER_EU) void k_pass(const PassPa
                     RT_DBG_MARK(6);
                     const float lum = rt_maxf(hc.x, rt_maxf(hc.y, hc.z));
                     bool alive = true;
-                    if (depth >= P.rr_limit) {                      // render.rs:149-156
-                        const float rq = rt_maxf(1.0f - lum, 0.05f);
-                        if (pcg_random_float(st, pinc) > rq) {
-                            const float s = 1.0f / (1.0f - rq);
-                            hc.x = hc.x * s; hc.y = hc.y * s; hc.z = hc.z * s;
-                        } else {
+                    const bool roulette = depth >= P.rr_limit;      // render.rs:149-156
+                    float rq = 0.0f;
+                    if (roulette) {
+                        rq = rt_maxf(1.0f - lum, 0.05f);
+                        if (!(pcg_random_float(st, pinc) > rq)) {
                             vr = em.x; vg = em.y; vb = em.z;
                             alive = false;
                         }
@@ -787,8 +788,20 @@ __global__ __launch_bounds__(RT_BLOCK, RT_WAVES_PER_EU) void k_pass(const PassPa
                             if (depth + 1u > P.max_depth) {
                                 // every child returns black without an intersection (render.rs:137-139)
                                 // but its two scatter draws are consumed (render.rs:161)
-                                st = st * P.skip_mult + pinc * P.skip_plus;
-                                const float cr = 0.0f + hc.x * 0.0f, cg = 0.0f + hc.y * 0.0f, cb = 0.0f + hc.z * 0.0f;
+                                st = st * P.skip_mult + pskip;
+                                // hit_color only meets zeros here: 0 + (hit_color * 1/(1-q)) * 0 is +0 for every
+                                // finite product, and 1/(1-q) <= 2^24 (q < 1 where the roulette was survived); the
+                                // survivor's divide is only paid where hit_color is not that tame
+                                const float big = 1.0e12f;
+                                const bool tame = __builtin_fabsf(hc.x) < big && __builtin_fabsf(hc.y) < big && __builtin_fabsf(hc.z) < big;
+                                float cr = 0.0f, cg = 0.0f, cb = 0.0f;
+                                if (!tame) {
+                                    if (roulette) {
+                                        const float s = 1.0f / (1.0f - rq);
+                                        hc.x = hc.x * s; hc.y = hc.y * s; hc.z = hc.z * s;
+                                    }
+                                    cr = 0.0f + hc.x * 0.0f; cg = 0.0f + hc.y * 0.0f; cb = 0.0f + hc.z * 0.0f;
+                                }
                                 vr = em.x + cr * P.inv_num_of_rays;
                                 vg = em.y + cg * P.inv_num_of_rays;
                                 vb = em.z + cb * P.inv_num_of_rays;
@@ -797,6 +810,10 @@ __global__ __launch_bounds__(RT_BLOCK, RT_WAVES_PER_EU) void k_pass(const PassPa
                                 // the hit opens: world_point and normal (src/shape.rs:88-95, :134-138, :175-182,
                                 // :205-209), then it becomes the current level
                                 leaf = false;
+                                if (roulette) {
+                                    const float s = 1.0f / (1.0f - rq);
+                                    hc.x = hc.x * s; hc.y = hc.y * s; hc.z = hc.z * s;
+                                }
                                 const Rows3 MW = load_rows(mrows[best].m);
                                 const Rows3 IW = load_rows(scan[best].inv);
                                 const Vec3 wp = rows_point<AFFINE>(MW, AFFINE ? nullptr : g_wrows[best].m_w, hx, hy, hz);
