@@ -205,7 +205,8 @@ int rt_pcg_random(const uint64_t* init_state, const uint64_t* init_seq, uint64_t
                   uint32_t n_draws, uint32_t* out);
 
 /* Evaluate include/rt_strict_math.h on the GPU (fn: 0 sin, 1 cos, 2 atan2(y=a,x=b), 3 acos,
- * 4 a/b, 5 sqrt(a)); used to prove host/device bit-equality of the shared math. */
+ * 4 a/b, 5 sqrt(a) as the render kernels compute it, 6 its short form for a == 0 or a >= 2^-96);
+ * used to prove host/device bit-equality of the shared math. */
 int rt_strict_math_eval(int fn, const float* a, const float* b, uint64_t n, float* out);
 
 #ifdef __cplusplus

@@ -128,6 +128,28 @@ __device__ __forceinline__ Vec3 xform_vector(const float* __restrict__ M, float 
     return r;
 }
 // ---------------------------------------------------------------------------------------------
+// Correctly rounded f32 sqrt without the compiler's denormal-range prologue/epilogue: the same
+// v_sqrt_f32 + one-ulp-neighbour residual test the compiler expands __builtin_sqrtf to, minus the
+// 2^32 pre-scaling it needs only for x < 2^-96 and the zero/inf class select (0, +inf and NaN fall
+// through the residual tests unchanged).  The caller guarantees x == 0 or x >= 2^-96.
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ float sqrt_rn_normal(float x) {
+    const float s = __builtin_amdgcn_sqrtf(x);
+    const float s_dn = __uint_as_float(__float_as_uint(s) - 1u);
+    const float s_up = __uint_as_float(__float_as_uint(s) + 1u);
+    const float r_dn = __builtin_fmaf(-s_dn, s, x);
+    const float r_up = __builtin_fmaf(-s_up, s, x);
+    float r = (r_dn <= 0.0f) ? s_dn : s;
+    r = (r_up > 0.0f) ? s_up : r;
+    return r;
+}
+// sqrt for any x: the short form unless some lane of the wave holds a tiny positive x (wave-uniform branch)
+__device__ __forceinline__ float sqrt_rn(float x) {
+    if (__ballot(x > 0.0f && x < 0x1.0p-96f) != 0ull) return __builtin_sqrtf(x);
+    return sqrt_rn_normal(x);
+}
+
+// ---------------------------------------------------------------------------------------------
 // Shape::ray_intersection, candidate part: only `t` is produced here; the HitRecord of the final
 // winner is built once by hit_record() below (result-identical: World keeps one record).
 // ---------------------------------------------------------------------------------------------
@@ -141,7 +163,7 @@ __device__ __forceinline__ bool sphere_t_nb(Vec3 o, Vec3 d, float tmin, float tm
     const float b = 2.0f * (o.x * d.x + o.y * d.y + o.z * d.z);
     const float c = (o.x * o.x + o.y * o.y + o.z * o.z) - 1.0f;
     const float delta = b * b - 4.0f * a * c;
-    const float sqrt_delta = __builtin_sqrtf(delta);
+    const float sqrt_delta = sqrt_rn(delta);
     const float a2 = 2.0f * a;
     const float t1 = (-b - sqrt_delta) / a2;
     const float t2 = (-b + sqrt_delta) / a2;
@@ -330,8 +352,9 @@ __device__ __forceinline__ Vec3 diffuse_scatter_dir(float rf0, float rf1, Vec3 n
     const float b = n.x * n.y * a;
     const float e1x = 1.0f + sign * n.x * n.x * a, e1y = sign * b, e1z = -sign * n.x;
     const float e2x = b, e2y = sign + n.y * n.y * a, e2z = -n.y;
-    const float cos_theta = __builtin_sqrtf(rf0);
-    const float sin_theta = __builtin_sqrtf(1.0f - rf0);
+    // rf0 = k * 2^-32 rounded to f32, in {0} U [2^-32, 1]; 1 - rf0 in {0} U [2^-24, 1]
+    const float cos_theta = sqrt_rn_normal(rf0);
+    const float sin_theta = sqrt_rn_normal(1.0f - rf0);
     const float phi = 6.2831854820251465f * rf1;  // (2.0 * PI) * pcg.1
     float sn, cs;
     rt_sincosf(phi, &sn, &cs);

@@ -1224,6 +1224,8 @@ __global__ __launch_bounds__(RT_BLOCK) void k_math(int fn, const float* __restri
         case 2: r = rt_atan2f(a[i], b[i]); break;
         case 3: r = rt_acosf(a[i]); break;
         case 4: r = a[i] / b[i]; break;
+        case 5: r = sqrt_rn(a[i]); break;                 // the hot path's sqrt (rt_device.h)
+        case 6: r = sqrt_rn_normal(a[i]); break;          // its short form: 0, or >= 2^-96
         default: r = __builtin_sqrtf(a[i]); break;
     }
     out[i] = r;

@@ -99,6 +99,13 @@ def test_strict_math_host_device_bit_equal():
     with np.errstate(all="ignore"):
         assert_bit_equal(_gpu_math(4, a, b), O.math_eval(4, a, b), "div")
         assert_bit_equal(_gpu_math(5, np.abs(a)), O.math_eval(5, np.abs(a)), "sqrt")
+        # the short form the scatter code uses (no denormal-range scaling): exact for 0, +inf and x >= 2^-96
+        nrm = np.abs(a)
+        nrm = np.where(np.isfinite(nrm) & (nrm >= np.float32(2.0**-96)), nrm, np.float32(0.0)).astype(np.float32)
+        nrm[:6] = [0.0, 1.0, np.inf, 2.0**-96, 2.0**-32, np.float32(1.0) - np.float32(2.0**-24)]
+        assert_bit_equal(_gpu_math(6, nrm), O.math_eval(5, nrm), "sqrt, normal range")
+        assert_bit_equal(_gpu_math(6, rf), O.math_eval(5, rf), "sqrt(rf)")
+        assert_bit_equal(_gpu_math(6, (np.float32(1.0) - rf).astype(np.float32)), O.math_eval(5, (np.float32(1.0) - rf).astype(np.float32)), "sqrt(1 - rf)")
 
 
 # ---- World::ray_intersection (src/shape.rs:223-568, src/world.rs:62-92) ------------------------
