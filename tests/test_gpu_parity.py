@@ -5,6 +5,7 @@ definition the kernels use), so every f32 of every pixel, hit record and PCG sta
 and the ray counters must match exactly.  Every test here needs a real MI355X.
 """
 import ctypes as C
+import os
 import math
 
 import numpy as np
@@ -50,6 +51,21 @@ def check_image(world, cam, renderer, w, h, **kw):
     assert_bit_equal(g, o, "image")
     for k in ("rays", "samples", "sphere_tests", "plane_tests", "diffuse_scatters", "specular_scatters"):
         assert gs[k] == os_[k], (k, gs[k], os_[k])
+    if isinstance(renderer, ra.PathTracer):
+        # the same frame through the throughput schedule (one pass, one lane per pixel: the k_pass FAST variant
+        # where the scene allows it; small frames would otherwise run teams)
+        old = os.environ.get("RUSTRACER_MAX_TEAM")
+        os.environ["RUSTRACER_MAX_TEAM"] = "1"
+        try:
+            g1, gs1 = gpu_render(world, cam, renderer, w, h, schedule=(0,), **kw)
+        finally:
+            if old is None:
+                del os.environ["RUSTRACER_MAX_TEAM"]
+            else:
+                os.environ["RUSTRACER_MAX_TEAM"] = old
+        assert_bit_equal(g1.cpu().numpy(), o, "image, one-pass schedule")
+        for k in ("rays", "samples", "diffuse_scatters", "specular_scatters"):
+            assert gs1[k] == os_[k], ("one-pass", k, gs1[k], os_[k])
     return g, gs
 
 
