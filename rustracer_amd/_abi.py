@@ -7,8 +7,8 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-# RUSTRACER_AMD_LIB: diagnostics only (an experimental build of the same library)
-LIB_PATH = os.environ.get("RUSTRACER_AMD_LIB") or os.path.join(_HERE, "librustracer_amd.so")
+# RUSTRACER_AMD_SO: diagnostics only (an experimental build of the same library)
+LIB_PATH = os.environ.get("RUSTRACER_AMD_SO") or os.path.join(_HERE, "librustracer_amd.so")
 
 # enums (include/rustracer_amd.h)
 RT_SHAPE_SPHERE, RT_SHAPE_PLANE = 0, 1

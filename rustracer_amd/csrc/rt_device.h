@@ -271,6 +271,127 @@ __device__ __forceinline__ int scan_closest_hit_g(const DScan* __restrict__ scan
     return best;
 }
 
+// ---------------------------------------------------------------------------------------------
+// Exact-winner bounding volume hierarchy for scenes too large for the linear scan to
+// stay in LDS.  World::ray_intersection's result is min over the hits by (t, index) -- the linear scan's
+// strict `<` keeps the earliest shape on ties -- so any traversal order gives the reference's winner as
+// long as (1) every shape runs the SAME object-space test (sphere_t_nb / plane_t_nb on its own rows) and
+// (2) no shape whose f32 test can report a hit is culled.  (2) is the delicate part: far from a small
+// sphere the f32 discriminant is dominated by rounding, and the reference "hits" rays that pass well
+// outside it.  With eps = 2^-24, rho = |invm 3x3|_F, G = (rho |m 3x3|_F)^2, D >= |origin - any point of
+// the shape's box| and W >= |origin| + |centre| (any norms >= the Euclidean ones), forward error analysis
+// of o' = T^-1 o, d' = T^-1 d, a, b, c and delta = b*b - 4ac gives: delta computed > 0 only if the ray
+// passes the unit sphere in object space within radius sqrt(1 + S),
+//     S <= eps * G * rho^2 * D * (38 D + 28 W) + 18 eps G
+// and the reported hit point lies in that inflated ball too.  A node is culled only if the ray misses its
+// box grown by hmax * (sqrt(1 + 2 S) - 1) (2x the bound, S from the node's maxima) plus 1e-6 W for the
+// slab arithmetic itself, or enters it beyond the best t so far by a margin.  Planes and shapes with
+// projective matrices are unbounded: they are tested for every ray.  Rays with a non-finite component take
+// the linear scan (a NaN t wins ties by order there).
+// ---------------------------------------------------------------------------------------------
+struct __attribute__((aligned(16))) DBvhNode {
+    float cx, cy, cz, hmax;   // box centre; largest half-extent of a shape below this node
+    float hx, hy, hz, q;      // box half-extents; max of G * rho^2 below
+    uint32_t skip;            // next node once this subtree is done or culled (DFS order: first child = this + 1)
+    uint32_t first, count;    // leaf: entries [first, first + count) of the leaf shape list; inner node: count == 0
+    float g0;                 // 40 eps * max G below
+};
+static_assert(sizeof(DBvhNode) == 48, "DBvhNode layout");
+
+struct DBvh {
+    const DBvhNode* nodes;
+    const uint32_t* leaf_shapes;
+    const uint32_t* unbounded;   // shapes outside the hierarchy, ascending
+    uint32_t n_nodes, n_unbounded;
+};
+
+template <bool AFFINE>
+__device__ __forceinline__ int bvh_closest_hit(const DBvh B, const DScan* __restrict__ scan, const DWRows* __restrict__ wrows,
+                                               uint32_t n_shapes, Vec3 ro, Vec3 rd, float tmin, float tmax,
+                                               float& best_t, Vec3& best_o, Vec3& best_d, uint32_t& best_kind) {
+    const bool finite = (__builtin_fabsf(ro.x) < __builtin_inff()) && (__builtin_fabsf(ro.y) < __builtin_inff()) &&
+                        (__builtin_fabsf(ro.z) < __builtin_inff()) && (__builtin_fabsf(rd.x) < __builtin_inff()) &&
+                        (__builtin_fabsf(rd.y) < __builtin_inff()) && (__builtin_fabsf(rd.z) < __builtin_inff());
+    if (__ballot(!finite) != 0ull)
+        return scan_closest_hit_g<AFFINE, 2>(scan, wrows, n_shapes, ro, rd, tmin, tmax, best_t, best_o, best_d, best_kind);
+    int best = -1;
+    best_t = 0.0f;
+    best_kind = 0u;
+    best_o = {0.f, 0.f, 0.f};
+    best_d = {0.f, 0.f, 0.f};
+    // one shape's own test; the winner is the minimum by (t, index)
+    auto test_shape = [&](uint32_t i) {
+        const Rows3 R = load_rows(scan[i].inv);
+        const uint32_t kind = scan[i].kind;
+        const Vec3 o = rows_point<AFFINE>(R, AFFINE ? nullptr : wrows[i].inv_w, ro.x, ro.y, ro.z);
+        const Vec3 d = rows_vector(R, rd.x, rd.y, rd.z);
+        float t = 0.0f;
+        bool hit;
+        if (kind == RT_SHAPE_SPHERE) hit = sphere_t_nb(o, d, tmin, tmax, t);
+        else hit = plane_t_nb(o, d, tmin, tmax, t);
+        if (hit && (best < 0 || t < best_t || (t == best_t && (int)i < best))) {
+            best = (int)i;
+            best_t = t;
+            best_o = o;
+            best_d = d;
+            best_kind = kind;
+        }
+    };
+    for (uint32_t u = 0; u < B.n_unbounded; ++u) test_shape(B.unbounded[u]);
+
+    const float EPS = 5.9604645e-8f;
+    const float big = 1.0e30f;
+    const float idx = (__builtin_fabsf(rd.x) < 1.0e-30f) ? __builtin_copysignf(big, rd.x) : 1.0f / rd.x;
+    const float idy = (__builtin_fabsf(rd.y) < 1.0e-30f) ? __builtin_copysignf(big, rd.y) : 1.0f / rd.y;
+    const float idz = (__builtin_fabsf(rd.z) < 1.0e-30f) ? __builtin_copysignf(big, rd.z) : 1.0f / rd.z;
+    const float o1 = __builtin_fabsf(ro.x) + __builtin_fabsf(ro.y) + __builtin_fabsf(ro.z);
+    // "while-while" traversal: every lane walks inner nodes until it stands on a leaf whose box it passes (or is
+    // done), then the wave runs the shape tests of all those leaves together -- a lane's leaf visits are few, so
+    // the expensive tests execute a few times per ray instead of once per node step of the slowest lane.
+    uint32_t i = 0;
+    for (;;) {
+      uint32_t leaf_first = 0, leaf_count = 0;
+      while (i < B.n_nodes) {
+        const float4* np = reinterpret_cast<const float4*>(B.nodes + i);
+        const float4 n0 = np[0], n1 = np[1], n2 = np[2];
+        const float hsum = n1.x + n1.y + n1.z;
+        const float D1 = __builtin_fabsf(ro.x - n0.x) + __builtin_fabsf(ro.y - n0.y) + __builtin_fabsf(ro.z - n0.z) + hsum;
+        const float W = o1 + __builtin_fabsf(n0.x) + __builtin_fabsf(n0.y) + __builtin_fabsf(n0.z) + hsum;
+        const float S = EPS * n1.w * D1 * (80.0f * D1 + 60.0f * W) + n2.w;
+        // sqrt(1 + S) - 1 <= min(S, sqrt(S)); the v_sqrt_f32 estimate is padded by 1 %
+        const float grow = (S < 1.0f) ? S : __builtin_amdgcn_sqrtf(S) * 1.01f;
+#ifdef RT_BVH_NO_MARGIN   // experiment: how many reference hits a geometric (unpadded) hierarchy would lose
+        const float e = 0.0f * grow;
+#else
+        const float e = n0.w * grow + 1.0e-6f * W;
+#endif
+        const float ex = n1.x + e, ey = n1.y + e, ez = n1.z + e;
+        const float ax = (n0.x - ex - ro.x) * idx, bx = (n0.x + ex - ro.x) * idx;
+        const float ay = (n0.y - ey - ro.y) * idy, by = (n0.y + ey - ro.y) * idy;
+        const float az = (n0.z - ez - ro.z) * idz, bz = (n0.z + ez - ro.z) * idz;
+        const float tn = __builtin_fmaxf(__builtin_fmaxf(__builtin_fminf(ax, bx), __builtin_fminf(ay, by)), __builtin_fminf(az, bz));
+        const float tf = __builtin_fminf(__builtin_fminf(__builtin_fmaxf(ax, bx), __builtin_fmaxf(ay, by)), __builtin_fmaxf(az, bz));
+        const float slack = 1.0e-3f * __builtin_fabsf(tn) + 1.0e-4f;
+        bool pass = (tn <= tf) && (tf + 1.0e-3f * __builtin_fabsf(tf) + 1.0e-4f >= tmin) && (tn - slack <= tmax);
+        if (best >= 0 && tn - slack > best_t) pass = false;
+        const uint32_t skip = __float_as_uint(n2.x), first = __float_as_uint(n2.y), count = __float_as_uint(n2.z);
+        if (pass) {
+            i = i + 1u;
+            if (count != 0u) {
+                leaf_first = first;
+                leaf_count = count;
+                break;
+            }
+        } else {
+            i = skip;
+        }
+      }
+      if (__ballot(leaf_count != 0u) == 0ull) break;
+      for (uint32_t k = 0; k < leaf_count; ++k) test_shape(B.leaf_shapes[leaf_first + k]);
+    }
+    return best;
+}
+
 // HitRecord fields of the winner (src/shape.rs:134-142, :205-213) on the split layout.  want_geom
 // false skips world_point and normal (a node that cannot scatter never reads them).
 template <bool AFFINE>

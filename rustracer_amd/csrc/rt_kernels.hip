@@ -112,6 +112,7 @@ struct PassParams {
     uint32_t idle_div;               // refill once 1/idle_div of a wave's teams are idle
     uint32_t backlog;                // queue entries per team slot of the grid (>= 1): fewer, fuller waves
     PassCtl* ctl;
+    DBvh bvh;                        // exact-winner hierarchy of a scene read from HBM (n_nodes == 0: linear scan)
     float* qbuf[2];                  // SoA path-state queues [field][entry]; pass p reads (p-1)&1, writes p&1
     uint32_t q_capacity;
     const TeamTables* tables;
@@ -418,6 +419,15 @@ __global__ __launch_bounds__(RT_BLOCK, RT_WAVES_PER_EU) void k_pass(const PassPa
 #define RT_DBG_MARK(i) do { (void)dbg_prev; } while (0)
 #endif
 
+    // World::ray_intersection: the linear scan of the shape table, or the hierarchy of a large scene
+    auto closest_hit = [&](const Vec3 o, const Vec3 d, const float tmin, const float tmax, float& t, Vec3& lo, Vec3& ld,
+                           uint32_t& bkind) -> int {
+        if constexpr (!SCENE_LDS) {
+            if (P.bvh.n_nodes != 0u) return bvh_closest_hit<AFFINE>(P.bvh, g_scan, g_wrows, P.n_shapes, o, d, tmin, tmax, t, lo, ld, bkind);
+        }
+        return scan_closest_hit_g<AFFINE, RT_SCAN_GROUP>(scan, g_wrows, P.n_shapes, o, d, tmin, tmax, t, lo, ld, bkind);
+    };
+
     // ---------------------------------------------------------------------------------------------
     // one node: intersect + shade (render.rs:57-67, :76-89, :136-171)
     // ---------------------------------------------------------------------------------------------
@@ -433,7 +443,7 @@ __global__ __launch_bounds__(RT_BLOCK, RT_WAVES_PER_EU) void k_pass(const PassPa
         float t;
         Vec3 lo, ld;                 // the winner's object-space ray
         uint32_t bkind;
-        const int best = scan_closest_hit_g<AFFINE, RT_SCAN_GROUP>(scan, g_wrows, P.n_shapes, o, d, tmin, tmax, t, lo, ld, bkind);
+        const int best = closest_hit(o, d, tmin, tmax, t, lo, ld, bkind);
         R.traced = true;
         RT_DBG_MARK(2);
         if (best < 0) {
@@ -742,7 +752,7 @@ __global__ __launch_bounds__(RT_BLOCK, RT_WAVES_PER_EU) void k_pass(const PassPa
                 float t;
                 Vec3 lo, ld;
                 uint32_t bkind;
-                const int best = scan_closest_hit_g<AFFINE, RT_SCAN_GROUP>(scan, g_wrows, P.n_shapes, o, d, tmin, __builtin_inff(), t, lo, ld, bkind);
+                const int best = closest_hit(o, d, tmin, __builtin_inff(), t, lo, ld, bkind);
                 RT_DBG_MARK(2);
                 bool leaf = true;
                 float vr, vg, vb;                                   // what the ray returns, when it is a leaf
@@ -1174,7 +1184,7 @@ __global__ __launch_bounds__(RT_BLOCK, RT_WAVES_PER_EU) void k_pass(const PassPa
 // World::ray_intersection for a batch of rays, full HitRecord (src/world.rs:32-50).
 template <bool AFFINE>
 __global__ __launch_bounds__(RT_BLOCK) void k_intersect(const DScan* __restrict__ scan, const DMRows* __restrict__ mrows,
-                                                        const DWRows* __restrict__ wrows, uint32_t n_shapes,
+                                                        const DWRows* __restrict__ wrows, uint32_t n_shapes, const DBvh bvh,
                                                         const rt_ray* __restrict__ rays, uint64_t n, rt_hit* __restrict__ hits) {
     const uint64_t i = (uint64_t)blockIdx.x * RT_BLOCK + threadIdx.x;
     if (i >= n) return;
@@ -1184,7 +1194,9 @@ __global__ __launch_bounds__(RT_BLOCK) void k_intersect(const DScan* __restrict_
     float t;
     Vec3 lo, ld;
     uint32_t bkind;
-    const int best = scan_closest_hit_g<AFFINE, 2>(scan, wrows, n_shapes, ro, rd, r.tmin, r.tmax, t, lo, ld, bkind);
+    const int best = bvh.n_nodes != 0u
+                         ? bvh_closest_hit<AFFINE>(bvh, scan, wrows, n_shapes, ro, rd, r.tmin, r.tmax, t, lo, ld, bkind)
+                         : scan_closest_hit_g<AFFINE, 2>(scan, wrows, n_shapes, ro, rd, r.tmin, r.tmax, t, lo, ld, bkind);
     rt_hit h;
     h.hit = 0; h.shape = 0; h.t = 0.f;
     h.world_point[0] = h.world_point[1] = h.world_point[2] = 0.f;

@@ -1,5 +1,5 @@
 #!/bin/bash
-# tools/build_variant.sh NAME [extra hipcc flags...] -> tools/dbg/NAME.so (experiments; load with RUSTRACER_AMD_LIB)
+# tools/build_variant.sh NAME [extra hipcc flags...] -> tools/dbg/NAME.so (experiments; load with RUSTRACER_AMD_SO)
 set -e
 cd "$(dirname "$0")/../rustracer_amd/csrc"
 NAME=$1; shift
