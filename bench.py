@@ -3,8 +3,8 @@
 
 A step = one ImageTracer::fire_all_rays pass (one whole frame) with the scene already resident in
 HBM and the image left in HBM.  Steps are issued as launches of B frames (rt_render_frames: the
-frames of a launch share one pixel queue on the GPU) over F HIP streams, so B*F frames are in
-flight; every frame is rendered in full, nothing is cached between frames.  N GPUs split EVERY
+frames of a launch share one pixel queue on the GPU; default 16 per GPU) over F HIP streams (default 2),
+so B*F frames are in flight; every frame is rendered in full, nothing is cached between frames.  N GPUs split EVERY
 frame by row tiles dealt round-robin (strong scaling), one process per GPU, and one RCCL gather
 per launch brings the parts to rank 0, where rt_unpack_parts assembles the images.
 
@@ -28,11 +28,11 @@ INIT_STATE, INIT_SEQ = 42, 54
 EXPECTED_RAYS = 44180520            # oracle (strict math) ray count of this exact frame; tests/test_gpu_parity.py
 PEAK_FP32_VECTOR_TFLOPS = 157.3     # MI355X_MICROARCH.md: spec, packed FMA counted as 2 flop
 PEAK_STRICT_NOFMA_TFLOPS = 78.6     # same issue rate with unfused mul/add (the reference forbids FMA contraction)
-# HBM bytes per frame of the default configuration, from profiles/r01_rocprof_default_F3_B4.txt (rocprofv3
-# --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate passes, KB per dispatch of 4 frames: 11265 and 126180;
-# FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for gfx950): (2*11265 + 126180) KB / 4.  The
+# HBM bytes per frame of the default configuration, from profiles/r01b_rocprof_default_F2_B16.txt (rocprofv3
+# --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate passes, KB per dispatch of 16 frames: 15397 and 350150;
+# FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for gfx950): (2*15397 + 350150) KB / 16.  The
 # algorithmic minimum is the 24.9 MB image; the path is VALU-bound, not HBM-bound.
-TRAFFIC_BYTES_PER_FRAME = (2 * 11265 + 126180) * 1000 / 4
+TRAFFIC_BYTES_PER_FRAME = (2 * 15397 + 350150) * 1000 / 16
 
 
 def partition_rows(height, part, n_parts, tile_rows):

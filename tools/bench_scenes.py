@@ -39,9 +39,24 @@ def run(name, world, cam, renderer, w, h, aa, frames, reps, flops_per_ray):
 demo = demo_world()
 run("C1 demo onoff 640x480 aa1", demo, demo_camera(640, 480), ra.OnOffRenderer(demo, ra.BLACK, ra.WHITE), 640, 480, 1, 8, 20, 220)
 run("C2 demo flat 1280x960 aa4", demo, demo_camera(1280, 960), ra.FlatRenderer(demo, ra.BLACK), 1280, 960, 4, 2, 10, 220 + 62)
-fl = flake_world(True)
-run("C4 flake (228 shapes, checkered + image pigments) pathtracer n=10 d=3 3840x2160 aa1", fl, flake_camera(3840, 2160),
-    ra.PathTracer(fl, ra.BLACK, 10, 3, 3), 3840, 2160, 1, 1, 2, 60 * 227 + 40 + 62 + 46)
-rs = random_spheres_world(10000)
-run("C5 10002 shapes pathtracer n=10 d=3 960x540 aa1 (1/64 of 7680x4320, 1/16 of the samples per pixel)", rs,
-    random_spheres_camera(960, 540), ra.PathTracer(rs, ra.BLACK, 10, 3, 3), 960, 540, 1, 1, 1, 60 * 10001 + 40 + 62 + 46)
+# C4 / C5: the linear scan of World::ray_intersection (the roofline figure: every ray tests every shape) and the
+# exact-winner hierarchy (same image bit for bit; its skipped tests are NOT credited as algorithmic flops)
+for linear in (True, False):
+    if linear:
+        os.environ["RUSTRACER_NO_BVH"] = "1"
+    else:
+        os.environ.pop("RUSTRACER_NO_BVH", None)
+    how = "linear scan" if linear else "hierarchy"
+    fl = flake_world(True)
+    fl.device()                       # the scene (and its hierarchy, if enabled) is built here
+    run(f"C4 flake (228 shapes, checkered + image pigments) pathtracer n=10 d=3 3840x2160 aa1, {how}", fl,
+        flake_camera(3840, 2160), ra.PathTracer(fl, ra.BLACK, 10, 3, 3), 3840, 2160, 1, 1, 2,
+        (60 * 227 + 40 + 62 + 46) if linear else 0)
+    rs = random_spheres_world(10000)
+    rs.device()
+    run(f"C5 10002 shapes pathtracer n=10 d=3 960x540 aa1 (1/64 of 7680x4320, 1/16 of the samples per pixel), {how}", rs,
+        random_spheres_camera(960, 540), ra.PathTracer(rs, ra.BLACK, 10, 3, 3), 960, 540, 1, 1, 1,
+        (60 * 10001 + 40 + 62 + 46) if linear else 0)
+    if not linear:
+        run(f"C5 10002 shapes pathtracer n=10 d=3 1920x1080 aa1, {how}", rs, random_spheres_camera(1920, 1080),
+            ra.PathTracer(rs, ra.BLACK, 10, 3, 3), 1920, 1080, 1, 1, 1, 0)
