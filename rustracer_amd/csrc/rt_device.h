@@ -278,12 +278,13 @@ __device__ __forceinline__ int scan_closest_hit_g(const DScan* __restrict__ scan
 // long as (1) every shape runs the SAME object-space test (sphere_t_nb / plane_t_nb on its own rows) and
 // (2) no shape whose f32 test can report a hit is culled.  (2) is the delicate part: far from a small
 // sphere the f32 discriminant is dominated by rounding, and the reference "hits" rays that pass well
-// outside it.  With eps = 2^-24, rho = |invm 3x3|_F, G = (rho |m 3x3|_F)^2, D >= |origin - any point of
-// the shape's box| and W >= |origin| + |centre| (any norms >= the Euclidean ones), forward error analysis
-// of o' = T^-1 o, d' = T^-1 d, a, b, c and delta = b*b - 4ac gives: delta computed > 0 only if the ray
-// passes the unit sphere in object space within radius sqrt(1 + S),
-//     S <= eps * G * rho^2 * D * (38 D + 28 W) + 18 eps G
-// and the reported hit point lies in that inflated ball too.  A node is culled only if the ray misses its
+// outside it.  With eps = 2^-24, rho2 / rhoF = spectral / Frobenius norm of invm's 3x3, kF = rhoF * (spectral
+// norm of m's 3x3), D >= |origin - any point of the shape's box| and W >= |origin| + |centre| (Euclidean),
+// forward error analysis of o' = T^-1 o (|do'| <= 4 eps rhoF W), d' = T^-1 d (|dd'| <= 3 eps kF |d'|), a, b, c
+// and delta = b*b - 4ac gives |d delta| <= eps a [(48 kF + 68)|o'|^2 + 64 |o'| rhoF W + 24 kF + 28], i.e. delta
+// computed > 0 only if the ray passes the unit sphere in object space within radius sqrt(1 + S),
+//     S <= eps [(12 kF + 17) rho2^2 D^2 + 16 rho2 rhoF D W + 6 kF + 7]
+// and the reported hit point lies in a ball of that order too.  A node is culled only if the ray misses its
 // box grown by hmax * (sqrt(1 + 2 S) - 1) (2x the bound, S from the node's maxima) plus 1e-6 W for the
 // slab arithmetic itself, or enters it beyond the best t so far by a margin.  Planes and shapes with
 // projective matrices are unbounded: they are tested for every ray.  Rays with a non-finite component take
@@ -291,10 +292,11 @@ __device__ __forceinline__ int scan_closest_hit_g(const DScan* __restrict__ scan
 // ---------------------------------------------------------------------------------------------
 struct __attribute__((aligned(16))) DBvhNode {
     float cx, cy, cz, hmax;   // box centre; largest half-extent of a shape below this node
-    float hx, hy, hz, q;      // box half-extents; max of G * rho^2 below
+    float hx, hy, hz, qa;     // box half-extents; max below of 2 (12 kF + 17) rho2^2
     uint32_t skip;            // next node once this subtree is done or culled (DFS order: first child = this + 1)
-    uint32_t first, count;    // leaf: entries [first, first + count) of the leaf shape list; inner node: count == 0
-    float g0;                 // 40 eps * max G below
+    uint32_t leaf;            // first * 32 + count: entries [first, first + count) of the leaf shape list; inner node: count == 0
+    float qb;                 // max below of 2 * 16 rho2 rhoF
+    float g0;                 // max below of 2 eps (6 kF + 7)
 };
 static_assert(sizeof(DBvhNode) == 48, "DBvhNode layout");
 
@@ -344,6 +346,7 @@ __device__ __forceinline__ int bvh_closest_hit(const DBvh B, const DScan* __rest
     const float idx = (__builtin_fabsf(rd.x) < 1.0e-30f) ? __builtin_copysignf(big, rd.x) : 1.0f / rd.x;
     const float idy = (__builtin_fabsf(rd.y) < 1.0e-30f) ? __builtin_copysignf(big, rd.y) : 1.0f / rd.y;
     const float idz = (__builtin_fabsf(rd.z) < 1.0e-30f) ? __builtin_copysignf(big, rd.z) : 1.0f / rd.z;
+    const float o2 = ro.x * ro.x + ro.y * ro.y + ro.z * ro.z;
     const float o1 = __builtin_fabsf(ro.x) + __builtin_fabsf(ro.y) + __builtin_fabsf(ro.z);
     // "while-while" traversal: every lane walks inner nodes until it stands on a leaf whose box it passes (or is
     // done), then the wave runs the shape tests of all those leaves together -- a lane's leaf visits are few, so
@@ -354,10 +357,14 @@ __device__ __forceinline__ int bvh_closest_hit(const DBvh B, const DScan* __rest
       while (i < B.n_nodes) {
         const float4* np = reinterpret_cast<const float4*>(B.nodes + i);
         const float4 n0 = np[0], n1 = np[1], n2 = np[2];
-        const float hsum = n1.x + n1.y + n1.z;
-        const float D1 = __builtin_fabsf(ro.x - n0.x) + __builtin_fabsf(ro.y - n0.y) + __builtin_fabsf(ro.z - n0.z) + hsum;
-        const float W = o1 + __builtin_fabsf(n0.x) + __builtin_fabsf(n0.y) + __builtin_fabsf(n0.z) + hsum;
-        const float S = EPS * n1.w * D1 * (80.0f * D1 + 60.0f * W) + n2.w;
+        // D: distance to the farthest corner of the box; (|o| + |c|)^2 <= 2 |o|^2 + 2 |c|^2 with c its farthest corner
+        // from the world origin; both squared sums padded by 1e-5 for their own rounding
+        const float fx = __builtin_fabsf(ro.x - n0.x) + n1.x, fy = __builtin_fabsf(ro.y - n0.y) + n1.y, fz = __builtin_fabsf(ro.z - n0.z) + n1.z;
+        const float gx = __builtin_fabsf(n0.x) + n1.x, gy = __builtin_fabsf(n0.y) + n1.y, gz = __builtin_fabsf(n0.z) + n1.z;
+        const float D2 = (fx * fx + fy * fy + fz * fz) * 1.00001f;
+        const float W2 = 2.0f * (o2 + gx * gx + gy * gy + gz * gz) * 1.00001f;
+        const float W = o1 + gx + gy + gz;                       // an upper bound of |o| + |c| for the slab padding
+        const float S = EPS * (n1.w * D2 + n2.z * __builtin_amdgcn_sqrtf(D2 * W2) * 1.01f) + n2.w;
         // sqrt(1 + S) - 1 <= min(S, sqrt(S)); the v_sqrt_f32 estimate is padded by 1 %
         const float grow = (S < 1.0f) ? S : __builtin_amdgcn_sqrtf(S) * 1.01f;
 #ifdef RT_BVH_NO_MARGIN   // experiment: how many reference hits a geometric (unpadded) hierarchy would lose
@@ -374,7 +381,7 @@ __device__ __forceinline__ int bvh_closest_hit(const DBvh B, const DScan* __rest
         const float slack = 1.0e-3f * __builtin_fabsf(tn) + 1.0e-4f;
         bool pass = (tn <= tf) && (tf + 1.0e-3f * __builtin_fabsf(tf) + 1.0e-4f >= tmin) && (tn - slack <= tmax);
         if (best >= 0 && tn - slack > best_t) pass = false;
-        const uint32_t skip = __float_as_uint(n2.x), first = __float_as_uint(n2.y), count = __float_as_uint(n2.z);
+        const uint32_t skip = __float_as_uint(n2.x), first = __float_as_uint(n2.y) >> 5, count = __float_as_uint(n2.y) & 31u;
         if (pass) {
             i = i + 1u;
             if (count != 0u) {
