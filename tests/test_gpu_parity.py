@@ -593,3 +593,25 @@ def test_cli_demo_matches_the_references_own_render_statistically(tmp_path):
     out2 = str(tmp_path / "again.png")
     assert cli.main(["convert", str(tmp_path / "demo.pfm"), out2]) == 0
     assert np.array_equal(np.asarray(Image.open(out2)), np.asarray(Image.open(out)))
+
+
+def test_cli_render_flake_matches_the_references_own_render_statistically(tmp_path):
+    """End to end through the scene-file parser, the exact-winner hierarchy (228 shapes) and tone mapping:
+    `render --width 1280 --height 720 --anti-aliasing 3 flake.yml` (README.md:276; the scene file is the emitted
+    counterpart of `cue eval flake.cue`) against the reference's examples/flake.png, condensed by
+    tools/make_golden_flake_png.py.  Random streams of the version that made the PNG are unknown, so pixels
+    differ individually: 40x40 block means must agree within 1/255 (measured 0.47 max, 0.046 mean) and the
+    whole-image mean within 0.02 (measured 0.008)."""
+    from PIL import Image
+    from rustracer_amd import cli
+    from rustracer_amd.scenes import flake_yml
+    import os
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "flake_png_soft.npz"))
+    scene = tmp_path / "flake.yml"
+    scene.write_text(flake_yml())
+    out = str(tmp_path / "flake.png")
+    assert cli.main(["render", str(scene), out, "--width", "1280", "--height", "720", "--anti-aliasing", "3"]) == 0
+    got = np.asarray(Image.open(out).convert("RGB")).astype(np.float64)
+    d = np.abs(got.reshape(18, 40, 32, 40, 3).mean((1, 3)) - g["block40"])
+    assert d.max() < 1.0 and d.mean() < 0.1, (d.max(), d.mean())
+    assert np.abs(got.mean((0, 1)) - g["mean_rgb"]).max() < 0.02
