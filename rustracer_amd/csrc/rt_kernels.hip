@@ -332,7 +332,9 @@ __global__ __launch_bounds__(RT_BLOCK, RT_WAVES_PER_EU) void k_pass(const PassPa
     // ---- LDS: [team tables][DScan x n][DMRows x n][DShade x n][DMaterial x n (one per shape)][recursion stack] ----
     TeamTables* lds_tab = reinterpret_cast<TeamTables*>(lds_raw);
     const uint32_t n_staged = SCENE_LDS ? P.n_shapes : 0u;
-    DScan* lds_scan = reinterpret_cast<DScan*>(reinterpret_cast<unsigned char*>(lds_raw) + (TEAMS ? sizeof(TeamTables) : 0));
+    // FAST keeps, in the slot of the team tables, the master PCG's jump by 0..63 pixels: (mult, plus) pairs
+    uint64_t* lds_jump = reinterpret_cast<uint64_t*>(lds_raw);
+    DScan* lds_scan = reinterpret_cast<DScan*>(reinterpret_cast<unsigned char*>(lds_raw) + ((TEAMS || FAST) ? sizeof(TeamTables) : 0));
     DMRows* lds_mrows = reinterpret_cast<DMRows*>(lds_scan + n_staged);
     DShade* lds_shade = reinterpret_cast<DShade*>(lds_mrows + n_staged);
     DMaterial* lds_mats = reinterpret_cast<DMaterial*>(lds_shade + n_staged);
@@ -363,7 +365,20 @@ __global__ __launch_bounds__(RT_BLOCK, RT_WAVES_PER_EU) void k_pass(const PassPa
             dst_m[i] = reinterpret_cast<const uint32_t*>(g_materials + g_scan[sh].material)[j];
         }
     }
-    if (TEAMS || SCENE_LDS) __syncthreads();
+    if (FAST) {
+        if (tid < 64u) {
+            // compose the power-of-two jumps of the bits of tid: s -> s * m + p
+            uint64_t m = 1, p = 0;
+            for (uint32_t i = 0; i < 6u; ++i)
+                if ((tid >> i) & 1u) {
+                    p = p * C0->pix_mult[i] + C0->pix_plus[i];
+                    m = m * C0->pix_mult[i];
+                }
+            lds_jump[2u * tid] = m;
+            lds_jump[2u * tid + 1u] = p;
+        }
+    }
+    if (TEAMS || SCENE_LDS || FAST) __syncthreads();
     const DScan* __restrict__ scan = SCENE_LDS ? lds_scan : g_scan;
     const DMRows* __restrict__ mrows = SCENE_LDS ? lds_mrows : g_mrows;
     const DShade* __restrict__ shade = SCENE_LDS ? lds_shade : g_shade;
@@ -653,7 +668,14 @@ __global__ __launch_bounds__(RT_BLOCK, RT_WAVES_PER_EU) void k_pass(const PassPa
                         // from the chunk's first pixel (a chunk that runs into the next frame restarts at 0)
                         const uint32_t gp = grow * C->width + gcol;
                         const bool same = (fr == my_base_f);
-                        const uint64_t s = master_jump(C, same ? my_base_state : C->master_state0, same ? gp - my_base_p : gp);
+                        const uint64_t jbase = same ? my_base_state : C->master_state0;
+                        const uint32_t jdelta = same ? gp - my_base_p : gp;
+                        uint64_t s;
+                        if (FAST && __ballot(jdelta >= 64u) == 0ull) {
+                            s = jbase * lds_jump[2u * jdelta] + lds_jump[2u * jdelta + 1u];   // the usual case: one step
+                        } else {
+                            s = master_jump(C, jbase, jdelta);
+                        }
                         mstate = s;
                         // seq = the u32 drawn after the pixel's 2*aa^2 jitter draws (imagetracer.rs:79)
                         const uint64_t sq = s * C->seq_mult + C->seq_plus;
