@@ -29,10 +29,11 @@ EXPECTED_RAYS = 44180520            # oracle (strict math) ray count of this exa
 PEAK_FP32_VECTOR_TFLOPS = 157.3     # MI355X_MICROARCH.md: spec, packed FMA counted as 2 flop
 PEAK_STRICT_NOFMA_TFLOPS = 78.6     # same issue rate with unfused mul/add (the reference forbids FMA contraction)
 # HBM bytes per frame of the default configuration, from profiles/r01b_rocprof_default_F2_B16.txt (rocprofv3
-# --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate passes, KB per dispatch of 16 frames: 15397 and 350150;
-# FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for gfx950): (2*15397 + 350150) KB / 16.  The
-# algorithmic minimum is the 24.9 MB image; the path is VALU-bound, not HBM-bound.
-TRAFFIC_BYTES_PER_FRAME = (2 * 15397 + 350150) * 1000 / 16
+# --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate passes, mean KB per dispatch over 5 dispatches that render
+# 1 + 16 + 3*16 = 65 frames: 15649 and 371850; FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for gfx950):
+# (2*15649 + 371850) KB * 5 / 65 = 31 MB.  The algorithmic minimum is the 24.9 MB image (12-byte pixel stores
+# fill cache lines partially); the path is VALU-bound, not HBM-bound.
+TRAFFIC_BYTES_PER_FRAME = (2 * 15649 + 371850) * 1000 * 5 / 65
 
 
 def partition_rows(height, part, n_parts, tile_rows):

@@ -5,6 +5,11 @@ print("== rocprofv3 --kernel-trace --stats -- python3 bench.py --steps 48 --warm
 for f in glob.glob(root + "/trace/*/*_kernel_stats.csv"):
     for r in csv.DictReader(open(f)):
         print(f"{r['Name'][:110]:110s} calls={r['Calls']:>4s} avg_ns={float(r['AverageNs']):12.0f} pct={r['Percentage']}")
+# per-dispatch durations of k_pass (launches differ in size: 1 instrumented frame, a warm-up remainder, full launches)
+for f in glob.glob(root + "/trace/*/*_kernel_trace.csv"):
+    durs = sorted((int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e6 for r in csv.DictReader(open(f)) if "k_pass" in r["Kernel_Name"])
+    if durs:
+        print("k_pass dispatch durations, ms: " + " ".join(f"{d:.3f}" for d in durs))
 print("\n== PMC (mean per dispatch) ==")
 for d in ("pmc1", "pmc2", "pmc3", "pmc4"):
     for f in glob.glob(f"{root}/{d}/*/*_counter_collection.csv"):
