@@ -1203,6 +1203,140 @@ __global__ __launch_bounds__(RT_BLOCK, RT_WAVES_PER_EU) void k_pass(const PassPa
 #undef K_PASS
 #undef K_DEBUG
 
+// The renderers without recursion (OnOff, Flat, Dummy: src/render.rs:57-89, :178-185) as a plain image kernel:
+// one lane per pixel, its aa^2 samples in order (imagetracer.rs:112-123).  Every sample costs the same, so no
+// queue and no refill: the master PCG of the lane's pixel is the wave's first pixel (scalar unit) jumped ahead by
+// the lane's offset (LDS table: one step in the usual case), then per sample two jitter draws, fire_ray, the
+// closest hit and the renderer's colour.
+template <bool AFFINE, bool SCENE_LDS>
+__global__ __launch_bounds__(RT_BLOCK) void k_simple(const PassParams P, const DScan* __restrict__ g_scan,
+                                                     const DWRows* __restrict__ g_wrows, const DShade* __restrict__ g_shade,
+                                                     const DMaterial* __restrict__ g_materials, const float* __restrict__ texels) {
+    extern __shared__ float4 lds_raw[];
+    ColdParams C = cold_params();
+    const uint32_t tid = threadIdx.x;
+    uint64_t* lds_jump = reinterpret_cast<uint64_t*>(lds_raw);                    // 64 x (mult, plus)
+    DScan* lds_scan = reinterpret_cast<DScan*>(reinterpret_cast<unsigned char*>(lds_raw) + 1024);
+    const uint32_t n_staged = SCENE_LDS ? P.n_shapes : 0u;
+    DShade* lds_shade = reinterpret_cast<DShade*>(lds_scan + n_staged);
+    DMaterial* lds_mats = reinterpret_cast<DMaterial*>(lds_shade + n_staged);
+    if (tid < 64u) {
+        uint64_t m = 1, p = 0;
+        for (uint32_t i = 0; i < 6u; ++i)
+            if ((tid >> i) & 1u) {
+                p = p * C->pix_mult[i] + C->pix_plus[i];
+                m = m * C->pix_mult[i];
+            }
+        lds_jump[2u * tid] = m;
+        lds_jump[2u * tid + 1u] = p;
+    }
+    if (SCENE_LDS) {
+        uint32_t* dst_s = reinterpret_cast<uint32_t*>(lds_scan);
+        const uint32_t* src_s = reinterpret_cast<const uint32_t*>(g_scan);
+        constexpr uint32_t SW = sizeof(DScan) / 4;
+        for (uint32_t i = tid; i < n_staged * SW; i += RT_BLOCK) {
+            const uint32_t sh = i / SW, j = i - sh * SW;
+            dst_s[i] = (j == 13u) ? sh : src_s[i];        // staged materials are indexed by shape
+        }
+        uint32_t* dst_h = reinterpret_cast<uint32_t*>(lds_shade);
+        const uint32_t* src_h = reinterpret_cast<const uint32_t*>(g_shade);
+        for (uint32_t i = tid; i < n_staged * (uint32_t)(sizeof(DShade) / 4); i += RT_BLOCK) dst_h[i] = src_h[i];
+        uint32_t* dst_m = reinterpret_cast<uint32_t*>(lds_mats);
+        constexpr uint32_t MW = sizeof(DMaterial) / 4;
+        for (uint32_t i = tid; i < n_staged * MW; i += RT_BLOCK) {
+            const uint32_t sh = i / MW, j = i - sh * MW;
+            dst_m[i] = reinterpret_cast<const uint32_t*>(g_materials + g_scan[sh].material)[j];
+        }
+    }
+    __syncthreads();
+    const DScan* __restrict__ scan = SCENE_LDS ? lds_scan : g_scan;
+    const DShade* __restrict__ shade = SCENE_LDS ? lds_shade : g_shade;
+    const DMaterial* __restrict__ mats = SCENE_LDS ? lds_mats : g_materials;
+
+    const uint32_t n_items = P.n_items;
+    const uint32_t i_raw = blockIdx.x * RT_BLOCK + tid;
+    const uint32_t i = i_raw < n_items ? i_raw : n_items - 1u;      // lanes past the end redo the last pixel, unstored
+    const uint32_t i0r = (uint32_t)__builtin_amdgcn_readfirstlane((int)(i_raw & ~63u));
+    const uint32_t i0 = i0r < n_items ? i0r : n_items - 1u;
+    uint32_t f0, lq0, r0, c0;
+    local_to_global(C, i0, f0, lq0, r0, c0);
+    const uint32_t base_f = (uint32_t)__builtin_amdgcn_readfirstlane((int)f0);
+    const uint32_t base_p = (uint32_t)__builtin_amdgcn_readfirstlane((int)(r0 * C->width + c0));
+    const uint64_t base_state = master_state_at(C, base_p);
+    uint32_t fr, lq, grow, gcol;
+    local_to_global(C, i, fr, lq, grow, gcol);
+    const uint32_t gp = grow * C->width + gcol;
+    const bool same = (fr == base_f) && (gp >= base_p);
+    const uint64_t jbase = same ? base_state : C->master_state0;
+    const uint32_t jdelta = same ? gp - base_p : gp;
+    uint64_t ms;
+    if (__ballot(jdelta >= 64u) == 0ull) ms = jbase * lds_jump[2u * jdelta] + lds_jump[2u * jdelta + 1u];
+    else ms = master_jump(C, jbase, jdelta);
+
+    const FrameEntry* F = frame_entry(C, fr);
+    const uint32_t aa2 = C->aa * C->aa;
+    float acc_r = 0.f, acc_g = 0.f, acc_b = 0.f;
+    for (uint32_t s = 0; s < aa2; ++s) {
+        Vec3 o, d;
+        primary_ray<AFFINE>(C, F, grow, gcol, s, ms, o, d);
+        float vr, vg, vb;
+        if (P.algorithm == RT_ALGO_DUMMY) {
+            vr = 1.0f; vg = 2.0f; vb = 3.0f;                          // render.rs:180-185
+        } else {
+            float t;
+            Vec3 lo, ld;
+            uint32_t bkind;
+            int best;
+            if (!SCENE_LDS && P.bvh.n_nodes != 0u)
+                best = bvh_closest_hit<AFFINE>(P.bvh, g_scan, g_wrows, P.n_shapes, o, d, 1e-5f, __builtin_inff(), t, lo, ld, bkind);
+            else
+                best = scan_closest_hit_g<AFFINE, RT_SCAN_GROUP>(scan, g_wrows, P.n_shapes, o, d, 1e-5f, __builtin_inff(), t, lo, ld, bkind);
+            if (best < 0) {
+                vr = P.bg[0]; vg = P.bg[1]; vb = P.bg[2];
+            } else if (P.algorithm == RT_ALGO_ONOFF) {
+                vr = P.fg[0]; vg = P.fg[1]; vb = P.fg[2];             // render.rs:61-66
+            } else {
+                // FlatRenderer: emitted + brdf colour at the hit's (u, v) (render.rs:80-85)
+                const float4* shp = reinterpret_cast<const float4*>(shade + best);
+                const float4 sh0 = shp[0], sh1 = shp[1];
+                Vec3 hc = {sh0.x, sh0.y, sh0.z};
+                Vec3 em = {sh1.x, sh1.y, sh1.z};
+                const uint32_t sflags = __float_as_uint(sh0.w);
+                if (sflags & 6u) {
+                    const float hx = lo.x + ld.x * t, hy = lo.y + ld.y * t, hz = lo.z + ld.z * t;   // inv_ray.at(t)
+                    float u, v;
+                    if (bkind == RT_SHAPE_SPHERE) {
+                        u = rt_atan2f(hy, hx) / 6.2831854820251465f;
+                        v = rt_acosf(hz) / 3.1415927410125732f;
+                        if (u < 0.0f) u += 1.0f;
+                    } else {
+                        u = hx - __builtin_floorf(hx);
+                        v = hy - __builtin_floorf(hy);
+                    }
+                    const DMaterial* M = mats + (SCENE_LDS ? (uint32_t)best : g_scan[best].material);
+                    if (sflags & 2u) hc = pigment_color(&M->brdf_pigment, texels, u, v);
+                    if (sflags & 4u) em = pigment_color(&M->emitted, texels, u, v);
+                }
+                vr = em.x + hc.x; vg = em.y + hc.y; vb = em.z + hc.z;   // render.rs:83-84
+            }
+        }
+        acc_r = acc_r + vr; acc_g = acc_g + vg; acc_b = acc_b + vb;     // imagetracer.rs:119
+    }
+    if (i_raw < n_items) {
+        float* out = F->out + 3ull * lq;
+        const float inv_samples = C->inv_samples;                       // imagetracer.rs:121
+        out[0] = acc_r * inv_samples;
+        out[1] = acc_g * inv_samples;
+        out[2] = acc_b * inv_samples;
+    }
+    if (i_raw == 0u) {
+        // every sample is one top-level solve and (but for Dummy) one World::ray_intersection
+        const unsigned long long n = (unsigned long long)n_items * aa2;
+        P.ctl->counters[0] = (P.algorithm == RT_ALGO_DUMMY) ? 0ull : n;
+        P.ctl->counters[1] = n;
+    }
+}
+
 // World::ray_intersection for a batch of rays, full HitRecord (src/world.rs:32-50).
 template <bool AFFINE>
 __global__ __launch_bounds__(RT_BLOCK) void k_intersect(const DScan* __restrict__ scan, const DMRows* __restrict__ mrows,
