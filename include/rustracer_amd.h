@@ -145,8 +145,9 @@ void rt_scene_destroy(rt_scene* scene);
  * passes: a pixel runs at most budgets[p] rays deep into its recursion in pass p, then its path state
  * is parked in HBM and picked up, compacted into full wavefronts, by pass p+1; the pass after the
  * last budget has no limit.  n_budgets == 0 restores the default (short passes: lowest latency of
- * one frame); budgets = {0} renders every pixel in one pass (best throughput when several frames
- * are in flight on different streams). */
+ * one frame; launches of more than about a dozen pixels per GPU lane run one pass by themselves);
+ * budgets = {0} renders every pixel in one pass (best throughput when several frames are in flight
+ * on different streams). */
 int rt_scene_set_schedule(rt_scene* scene, const uint32_t* budgets, uint32_t n_budgets);
 
 /* Number of pixels of `part` (rows * width), i.e. the length/3 of the buffer rt_render fills. */

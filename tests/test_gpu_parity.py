@@ -337,6 +337,15 @@ def test_c2_flat_aa4_demo():
     check_image(world, demo_camera(320, 240), ra.FlatRenderer(world, ra.BLACK), 320, 240, aa=4)
 
 
+def test_flat_and_onoff_frames_through_the_general_kernel_too(monkeypatch):
+    """k_simple renders these frames by default; k_pass must keep giving the same pixels (it serves
+    rt_renderer_solve for these renderers)."""
+    monkeypatch.setenv("RUSTRACER_NO_SIMPLE", "1")
+    world = demo_world()
+    check_image(world, demo_camera(160, 120), ra.FlatRenderer(world, ra.BLACK), 160, 120, aa=3)
+    check_image(world, demo_camera(160, 120), ra.OnOffRenderer(world, ra.BLACK, ra.WHITE), 160, 120)
+
+
 def test_c3_pathtracer_demo_small():
     world = demo_world()
     g, st = check_image(world, demo_camera(192, 108), ra.PathTracer(world, ra.BLACK, 10, 3, 3), 192, 108)

@@ -17,3 +17,16 @@ for name, sched in (("short passes + teams", ()), ("one pass (FAST)", (0,))):
         _abi.check(lib.rt_render(dev.handle, C.byref(cam), C.byref(rr), W, H, 42, 54, 1, None, img.data_ptr(), None, C.byref(st)))
         best = min(best, st.kernel_ms)
     print(f"{name:24s} kernel {best:.3f} ms  rays {st.rays}")
+# the literal drop-in call: host buffers in, host image out (scene upload, render, 24.9 MB D2H)
+import time
+import numpy as np
+from rustracer_amd.world import flatten_world
+flat = flatten_world(world)
+out = np.zeros((H, W, 3), dtype=np.float32)
+best = 1e9
+for _ in range(5):
+    st = _abi.rt_stats()
+    t0 = time.perf_counter()
+    _abi.check(lib.rt_fire_all_rays(*flat.args(), C.byref(cam), C.byref(rr), W, H, 42, 54, 1, out.ctypes.data_as(C.POINTER(C.c_float)), C.byref(st)))
+    best = min(best, (time.perf_counter() - t0) * 1e3)
+print(f"rt_fire_all_rays (host buffers) wall {best:.3f} ms, of which kernel {st.kernel_ms:.3f} ms")
