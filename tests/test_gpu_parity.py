@@ -550,6 +550,38 @@ def test_c5_random_spheres_10002_shapes():
         assert gs[k] == rs[k], k
 
 
+def test_hierarchy_scene_of_ellipsoids_mirrors_and_pigments_path_traced():
+    """A 300-shape scene (rotated / non-uniformly scaled spheres, mirrors, checkered and image pigments, two
+    planes, an enclosing sky) through every image kernel with the hierarchy on: flat (k_simple), path tracer in
+    the latency schedule and in one pass."""
+    rng = np.random.default_rng(23)
+    tex = ra.HdrImage(8, 5)
+    tex.pixels = rng.uniform(0, 1, (5, 8, 3)).astype(np.float32)
+    world = ra.World()
+    world.add(ra.Sphere(ra.scaling((80, 80, 80)), ra.Material(ra.DiffuseBRDF(ra.UniformPigment(ra.BLACK)), ra.UniformPigment((1.0, 0.9, 0.7)))))
+    world.add(ra.Plane(ra.translation((0, 0, -1)), ra.Material(ra.DiffuseBRDF(ra.CheckeredPigment((0.3, 0.5, 0.1), (0.1, 0.2, 0.5), 4)), ra.UniformPigment(ra.BLACK))))
+    for k in range(297):
+        c = (float(rng.uniform(-6, 14)), float(rng.uniform(-10, 10)), float(rng.uniform(-0.8, 4)))
+        r = float(rng.uniform(0.15, 0.9))
+        t = ra.translation(c) * ra.rotation_z(float(rng.uniform(0, 3))) * ra.rotation_y(float(rng.uniform(0, 3))) * \
+            ra.scaling((r, r * float(rng.uniform(0.4, 2.0)), r * float(rng.uniform(0.4, 2.0))))
+        col = tuple(float(x) for x in rng.uniform(0.1, 0.9, 3))
+        if k % 5 == 0:
+            brdf = ra.SpecularBRDF(ra.UniformPigment(col))
+        elif k % 5 == 1:
+            brdf = ra.DiffuseBRDF(ra.CheckeredPigment(col, (0.9, 0.9, 0.9), 6))
+        elif k % 5 == 2:
+            brdf = ra.DiffuseBRDF(ra.ImagePigment(tex))
+        else:
+            brdf = ra.DiffuseBRDF(ra.UniformPigment(col))
+        world.add(ra.Sphere(t, ra.Material(brdf, ra.UniformPigment(ra.BLACK))))
+    world.add(ra.Plane(ra.rotation_y(1.3) * ra.translation((0, 0, -30))))
+    assert len(world.shapes) == 300
+    cam = ra.PerspectiveCamera(1.0, 1.6, ra.translation((-4.0, 0.0, 1.5)))
+    check_image(world, cam, ra.FlatRenderer(world, ra.BLACK), 160, 100, aa=2)
+    check_image(world, cam, ra.PathTracer(world, ra.BLACK, 4, 3, 2), 160, 100)
+
+
 def test_render_frames_animation_in_one_launch():
     """rt_render_frames: frames with different cameras share one launch; each equals its own fire_all_rays."""
     import torch
