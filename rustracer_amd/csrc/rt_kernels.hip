@@ -742,6 +742,7 @@ __global__ __launch_bounds__(RT_BLOCK, RT_WAVES_PER_EU) void k_pass(const PassPa
             // writes the recursion state directly (no NodeOut record to merge) and a leaf is folded
             // where its value is known.
             // =================================================================================
+            if (K_DEBUG) { dbg_rounds += 1u; dbg_lanes += (uint32_t)__popcll(__ballot(busy)); }
             u_rays += (uint32_t)__popcll(__ballot(busy));           // every live lane traces one ray per round
             u_diffuse += (uint32_t)__popcll(__ballot(busy && lvl > 0u && cur_brdf == RT_BRDF_DIFFUSE));
             u_specular += (uint32_t)__popcll(__ballot(busy && lvl > 0u && cur_brdf != RT_BRDF_DIFFUSE));
