@@ -150,6 +150,11 @@ void rt_scene_destroy(rt_scene* scene);
  * on different streams). */
 int rt_scene_set_schedule(rt_scene* scene, const uint32_t* budgets, uint32_t n_budgets);
 
+/* How World::ray_intersection runs on this scene (no counterpart in the reference; diagnostics and tests):
+ * n_nodes > 0 means the exact-winner hierarchy is used (scenes of more than 96 shapes with at least 64
+ * bounded ones), n_unbounded is the number of shapes outside it that every ray tests.  0 on success. */
+int rt_scene_hierarchy_info(const rt_scene* scene, uint32_t* n_nodes, uint32_t* n_unbounded);
+
 /* Number of pixels of `part` (rows * width), i.e. the length/3 of the buffer rt_render fills. */
 uint64_t rt_partition_pixels(uint32_t width, uint32_t height, const rt_partition* part);
 

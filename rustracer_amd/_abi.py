@@ -84,6 +84,7 @@ SIGNATURES = {
     "rt_scene_destroy": (None, [C.c_void_p]),
     "rt_scene_set_schedule": (C.c_int, [C.c_void_p, P(C.c_uint32), C.c_uint32]),
     "rt_partition_pixels": (C.c_uint64, [C.c_uint32, C.c_uint32, P(rt_partition)]),
+    "rt_scene_hierarchy_info": (C.c_int, [C.c_void_p, P(C.c_uint32), P(C.c_uint32)]),
     "rt_render": (C.c_int, [C.c_void_p, P(rt_camera), P(rt_renderer), C.c_uint32, C.c_uint32,
                             C.c_uint64, C.c_uint64, C.c_uint32, P(rt_partition), C.c_void_p,
                             C.c_void_p, P(rt_stats)]),

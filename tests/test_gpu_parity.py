@@ -227,6 +227,9 @@ def test_hierarchy_returns_the_linear_scans_winner_on_adversarial_rays():
     rays.append(to_rt_ray(ra.Ray(origin=(math.nan, 0, 5), dir=(0, 0, -1))))
     rays.append(to_rt_ray(ra.Ray(origin=(0, 0, 50), dir=(0, 0, -1), tmin=1.0, tmax=30.0)))
     g = world.ray_intersections(rays)
+    nn, nu = C.c_uint32(), C.c_uint32()
+    _abi.check(_abi.lib().rt_scene_hierarchy_info(world.device().handle, C.byref(nn), C.byref(nu)))
+    assert nn.value > 200 and nu.value == 3, (nn.value, nu.value)   # in use; outside it: 2 planes + the projective sphere
     o = O.world_ray_intersection(flatten_world(world), rays, O.MATH_STRICT)
     for a, b in zip(g, o):
         _hits_equal(a, b)
