@@ -3,7 +3,8 @@
 
 A step = one ImageTracer::fire_all_rays pass (one whole frame) with the scene already resident in
 HBM and the image left in HBM.  Steps are issued as launches of B frames (rt_render_frames: the
-frames of a launch share one pixel queue on the GPU; default 16 per GPU) over F HIP streams (default 2),
+frames of a launch share one pixel queue on the GPU; default: the steps dealt evenly over the fewest launches
+of at most 64 frames) over F HIP streams (default 2),
 so B*F frames are in flight; every frame is rendered in full, nothing is cached between frames.  N GPUs split EVERY
 frame by row tiles dealt round-robin (strong scaling), one process per GPU, and one RCCL gather
 per launch brings the parts to rank 0, where rt_unpack_parts assembles the images.
@@ -71,8 +72,8 @@ def main():
     ap.add_argument("--tile-rows", type=int, default=1)
     ap.add_argument("--inflight", type=int, default=2, help="launches in flight on separate HIP streams (1..4)")
     ap.add_argument("--frames-per-launch", type=int, default=0,
-                    help="frames rendered by one rt_render_frames launch (default: 16 per GPU, at most 64: every "
-                         "GPU renders 1/N of each frame, so the launch keeps its size per GPU as N grows)")
+                    help="frames rendered by one rt_render_frames launch (default: the steps dealt evenly over the "
+                         "fewest launches of at most 64 frames)")
     ap.add_argument("--schedule", choices=["auto", "passes", "onepass"], default="auto",
                     help="rt_scene_set_schedule: 'passes' = short passes (lowest single-frame latency), 'onepass' = one "
                          "pass per launch (best throughput with many frames in flight); auto = onepass unless "
@@ -112,7 +113,16 @@ def main():
     rr = ra.PathTracer(scene, ra.BLACK, NUM_OF_RAYS, MAX_DEPTH, RR_LIMIT).flatten()
     dev = scene.device()          # World resident in HBM before the timed region
     F = max(1, min(args.inflight, 4))
-    B = max(1, min(args.frames_per_launch or 16 * world_size, 64))
+    if args.frames_per_launch:
+        B = max(1, min(args.frames_per_launch, 64))
+    else:
+        # the fewest launches of at most 64 frames, the steps dealt evenly over them: every launch ends with one
+        # drain of long pixels, and launches in flight on different streams drain together.  With several GPUs
+        # at least 4 launches, so that the gather of one overlaps the render of the next.
+        n_l = (args.steps + 63) // 64
+        if world_size > 1:
+            n_l = max(n_l, min(4, args.steps))
+        B = max(1, min((args.steps + n_l - 1) // n_l, 64))
     onepass = args.schedule == "onepass" or (args.schedule == "auto" and (F > 1 or B > 1))
     dev.set_schedule((0,) if onepass else ())
 
