@@ -591,6 +591,7 @@ def test_hierarchy_scene_of_ellipsoids_mirrors_and_pigments_path_traced():
     cam = ra.PerspectiveCamera(1.0, 1.6, ra.translation((-4.0, 0.0, 1.5)))
     check_image(world, cam, ra.FlatRenderer(world, ra.BLACK), 160, 100, aa=2)
     check_image(world, cam, ra.PathTracer(world, ra.BLACK, 4, 3, 2), 160, 100)
+    check_image(world, cam, ra.PathTracer(world, ra.BLACK, 3, 2, 1), 96, 60, aa=2, init_state=5, init_seq=77)
 
 
 def test_render_frames_animation_in_one_launch():
