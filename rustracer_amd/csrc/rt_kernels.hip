@@ -178,11 +178,14 @@ __device__ __forceinline__ uint64_t master_jump(ColdParams P, uint64_t s, uint32
 
 // Pass 0 hands out pixels in a strided order so that every wave sees a mix of cheap (sky) and
 // expensive image regions: queue entry h = (granule g, offset r) with 64-pixel granules; granule g
-// maps to pixel granule (g % 64) * stride + g / 64.  Entries past the last pixel are skipped.
+// maps to pixel granule s * stride + (g / 64 + s * (stride / 64)) % stride with s = g % 64.  Entries past
+// the last pixel are skipped.
 __device__ __forceinline__ uint32_t perm_entry(uint32_t h, uint32_t stride) {
     if (stride == 0u) return h;
-    const uint32_t g = h >> 6;
-    return (((g & 63u) * stride + (g >> 6)) << 6) | (h & 63u);
+    const uint32_t g = h >> 6, s = g & 63u;
+    uint32_t o = (g >> 6) + s * (stride >> 6);   // each stratum starts a 64th of a stratum further on, so strata
+    if (o >= stride) o -= stride;                // that begin at the same place in different frames do not sweep the image in step
+    return ((s * stride + o) << 6) | (h & 63u);
 }
 
 // n / d for every u32 n, d >= 1, with mg = {m', sh1, sh2} of d: one mul_hi instead of a ~25-instruction expansion
