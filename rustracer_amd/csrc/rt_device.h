@@ -287,8 +287,8 @@ __device__ __forceinline__ int scan_closest_hit_g(const DScan* __restrict__ scan
 // and the reported hit point lies in a ball of that order too.  A node is culled only if the ray misses its
 // box grown by hmax * (sqrt(1 + 2 S) - 1) (2x the bound, S from the node's maxima) plus 1e-6 W for the
 // slab arithmetic itself, or enters it beyond the best t so far by a margin.  Planes and shapes with
-// projective matrices are unbounded: they are tested for every ray.  Rays with a non-finite component take
-// the linear scan (a NaN t wins ties by order there).
+// projective matrices are unbounded: they are tested for every ray.  Rays with a non-finite component, and rays
+// for which an unbounded shape reports a hit at t = NaN, take the linear scan (a NaN t wins or loses by order there).
 // ---------------------------------------------------------------------------------------------
 struct __attribute__((aligned(16))) DBvhNode {
     float cx, cy, cz, hmax;   // box centre; largest half-extent of a shape below this node
@@ -340,6 +340,11 @@ __device__ __forceinline__ int bvh_closest_hit(const DBvh B, const DScan* __rest
         }
     };
     for (uint32_t u = 0; u < B.n_unbounded; ++u) test_shape(B.unbounded[u]);
+    // Plane::ray_intersection reports a hit whose t is NaN (its two rejections are comparisons that NaN fails,
+    // src/shape.rs:198-204); the linear scan then keeps that hit iff no earlier shape is hit at all, which is not
+    // a minimum over (t, index).  Only unbounded shapes can do this: such a wave takes the linear scan.
+    if (__ballot(best >= 0 && best_t != best_t) != 0ull)
+        return scan_closest_hit_g<AFFINE, 2>(scan, wrows, n_shapes, ro, rd, tmin, tmax, best_t, best_o, best_d, best_kind);
 
     const float EPS = 5.9604645e-8f;
     const float big = 1.0e30f;

@@ -1,0 +1,151 @@
+"""Randomised parity sweep: random scenes / cameras / renderers, HIP path vs the strict oracle, bit for bit.
+
+  python tools/fuzz_parity.py FIRST_SEED N_SEEDS        (needs a GPU; prints one line per scene, exits 1 on a mismatch)
+
+tests/test_gpu_parity.py::test_random_scenes runs a fixed handful of these seeds; this tool is for long sweeps.
+"""
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+import rustracer_amd as ra  # noqa: E402
+
+
+def random_pigment(rng, tex, bright=1.0):
+    k = rng.integers(0, 10)
+    col = tuple(float(x) * bright for x in rng.uniform(0.0, 1.0, 3))
+    if k < 6:
+        return ra.UniformPigment(col)
+    if k < 8:
+        return ra.CheckeredPigment(col, tuple(float(x) * bright for x in rng.uniform(0.0, 1.0, 3)), int(rng.integers(1, 12)))
+    return ra.ImagePigment(tex)
+
+
+def random_transform(rng, spread, rmin, rmax, projective=False, nasty=False):
+    c = tuple(float(x) for x in rng.uniform(-spread, spread, 3))
+    r = float(rng.uniform(rmin, rmax))
+    t = ra.translation(c)
+    if rng.random() < 0.6:
+        t = t * ra.rotation_z(float(rng.uniform(0, 360))) * ra.rotation_y(float(rng.uniform(0, 360))) * \
+            ra.rotation_x(float(rng.uniform(0, 360)))
+    if rng.random() < 0.5:
+        t = t * ra.scaling((r, r * float(rng.uniform(0.3, 3)), r * float(rng.uniform(0.3, 3))))
+    else:
+        t = t * ra.scaling((r, r, r))
+    if nasty and rng.random() < 0.25:
+        # extreme but legal inputs: huge / tiny / flat shapes (an infinite inverse), far-away centres
+        k = int(rng.integers(0, 5))
+        if k == 0:
+            t = t * ra.scaling((float(10 ** rng.uniform(-7, -3)),) * 3)
+        elif k == 1:
+            t = t * ra.scaling((float(10 ** rng.uniform(2, 7)),) * 3)
+        elif k == 2:
+            t = ra.translation(tuple(float(x) for x in rng.uniform(-1, 1, 3) * 10 ** rng.uniform(3, 9))) * t
+        elif k == 3:
+            sc = [1.0, 1.0, 1.0]
+            sc[int(rng.integers(0, 3))] = 0.0
+            with np.errstate(all="ignore"):
+                t = t * ra.scaling(tuple(sc))
+        else:
+            t = t * ra.scaling((float(10 ** rng.uniform(-3, 3)), float(10 ** rng.uniform(-3, 3)), float(10 ** rng.uniform(-3, 3))))
+    if projective:
+        # a last row other than [0,0,0,1]: the w divide of transformation.rs:185-193 (and an unbounded shape
+        # for the hierarchy)
+        m = np.array(t.m, dtype=np.float64).reshape(4, 4).copy()
+        m[3, 3] = float(rng.uniform(0.5, 2.0))
+        m[3, int(rng.integers(0, 3))] = float(rng.uniform(-0.2, 0.2))
+        if np.all(np.isfinite(m)) and abs(np.linalg.det(m)) > 1e-30:
+            with np.errstate(all="ignore"):
+                return ra.Transformation(m.astype(np.float32), np.linalg.inv(m).astype(np.float32))
+    return t
+
+
+def random_case(seed):
+    rng = np.random.default_rng(seed)
+    nasty = seed >= 1_000_000           # seeds from a million on also draw extreme transforms and colours
+    tex = ra.HdrImage(int(rng.integers(1, 9)), int(rng.integers(1, 9)))
+    tex.pixels = rng.uniform(0, 1, (tex.height, tex.width, 3)).astype(np.float32)
+    size_class = int(rng.integers(0, 4))
+    n_shapes = [int(rng.integers(1, 9)), int(rng.integers(9, 97)), int(rng.integers(97, 140)), int(rng.integers(140, 400))][size_class]
+    spread = [3.0, 6.0, 8.0, 12.0][size_class]
+    world = ra.World()
+    if rng.random() < 0.7:      # an emissive enclosure, so that paths return light
+        world.add(ra.Sphere(ra.scaling((60, 60, 60)), ra.Material(ra.DiffuseBRDF(ra.UniformPigment(ra.BLACK)), random_pigment(rng, tex))))
+    while len(world.shapes) < n_shapes:
+        emit = random_pigment(rng, tex, 0.5) if rng.random() < 0.15 else ra.UniformPigment(ra.BLACK)
+        pig = random_pigment(rng, tex)
+        brdf = ra.SpecularBRDF(pig) if rng.random() < 0.3 else ra.DiffuseBRDF(pig)
+        mat = ra.Material(brdf, emit)
+        u = rng.random()
+        if u < 0.08:
+            world.add(ra.Plane(random_transform(rng, spread, 0.5, 2.0, nasty=nasty), mat))
+        elif u < 0.11:
+            world.add(ra.Sphere(random_transform(rng, spread, 0.3, 1.5, projective=True, nasty=nasty), mat))
+        else:
+            world.add(ra.Sphere(random_transform(rng, spread, 0.2, 1.8, nasty=nasty), mat))
+        if rng.random() < 0.03 and len(world.shapes) < n_shapes:
+            world.add(world.shapes[-1])          # exact duplicate: the earlier index wins (world.rs:38)
+    w, h = int(rng.integers(1, 97)), int(rng.integers(1, 65))
+    cam_t = ra.translation(tuple(float(x) for x in rng.uniform(-4, 4, 3))) * ra.rotation_z(float(rng.uniform(0, 360))) * \
+        ra.rotation_y(float(rng.uniform(-40, 40)))
+    aspect = w / h if rng.random() < 0.7 else float(rng.uniform(0.5, 2.5))
+    if rng.random() < 0.75:
+        cam = ra.PerspectiveCamera(float(rng.uniform(0.4, 3.0)), aspect, cam_t)
+    else:
+        cam = ra.OrthogonalCamera(aspect, cam_t * ra.scaling((1.0, float(rng.uniform(1, 6)), float(rng.uniform(1, 6)))))
+    bg = tuple(float(x) for x in rng.uniform(0, 0.3, 3)) if rng.random() < 0.5 else ra.BLACK
+    if nasty and rng.random() < 0.2:
+        bg = (float("inf"), -1.0, float(rng.uniform(0, 1e30)))
+    k = int(rng.integers(0, 10))
+    if k == 0:
+        renderer = ra.OnOffRenderer(world)
+    elif k <= 2:
+        renderer = ra.FlatRenderer(world, bg)
+    else:
+        n = int(rng.choice([1, 2, 3, 4, 5, 10]))
+        d = int(rng.integers(0, 5))
+        while n ** d > 1500:
+            d -= 1
+        renderer = ra.PathTracer(world, bg, n, d, int(rng.integers(0, 6)))
+    aa = int(rng.choice([1, 1, 2, 3]))
+    # keep the oracle's linear scan to seconds: an upper bound of its shape tests
+    chain = 1
+    if isinstance(renderer, ra.PathTracer):
+        chain = sum(renderer.num_of_rays ** k for k in range(renderer.max_depth + 1))
+    while w * h * aa * aa * chain * len(world.shapes) > 4e8 and (w > 8 or h > 8):
+        w, h = max(w // 2, 1), max(h // 2, 1)
+    return world, cam, renderer, w, h, dict(init_state=int(rng.integers(0, 2**63)), init_seq=int(rng.integers(0, 2**63)), aa=aa)
+
+
+def describe(world, cam, renderer, w, h, kw):
+    r = type(renderer).__name__
+    if isinstance(renderer, ra.PathTracer):
+        r += f"(n={renderer.num_of_rays},d={renderer.max_depth},rr={renderer.russian_roulette_limit})"
+    return f"{len(world.shapes):3d} shapes {type(cam).__name__[:5]} {w}x{h} aa{kw['aa']} {r}"
+
+
+def main():
+    from test_gpu_parity import check_image
+    first, n = int(sys.argv[1]), int(sys.argv[2])
+    bad = 0
+    for seed in range(first, first + n):
+        case = random_case(seed)
+        t0 = time.perf_counter()
+        try:
+            _, st = check_image(*case[:5], **case[5])
+            print(f"seed {seed}: ok   {describe(*case)} rays {st['rays']} ({time.perf_counter() - t0:.1f} s)", flush=True)
+        except AssertionError as e:
+            bad += 1
+            print(f"seed {seed}: FAIL {describe(*case)}: {e}", flush=True)
+    print(f"{n - bad} of {n} scenes bit-identical", flush=True)
+    sys.exit(1 if bad else 0)
+
+
+if __name__ == "__main__":
+    main()
