@@ -596,7 +596,8 @@ def test_hierarchy_scene_of_ellipsoids_mirrors_and_pigments_path_traced():
 
 def test_random_scenes():
     """Random scenes (1-400 shapes: LDS and HBM tables, hierarchy, projective matrices, duplicates, every pigment and
-    BRDF), cameras, renderers and seeds from tools/fuzz_parity.py; sweeps of 3 150 ordinary and 2 000 extreme seeds ran clean on the MI355X."""
+    BRDF), cameras, renderers and seeds from tools/fuzz_parity.py, each also under a random pass schedule / team cap
+    and through the batch World::ray_intersection / Renderer::solve calls on adversarial rays; sweeps of 5 350 ordinary and 3 500 extreme seeds ran clean on the MI355X."""
     import sys
     sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
     import fuzz_parity
@@ -609,7 +610,8 @@ def test_random_scenes():
             warnings.simplefilter("ignore")
             case = fuzz_parity.random_case(seed)
         try:
-            check_image(*case[:5], **case[5])
+            fuzz_parity.check_case(seed, case)
+            fuzz_parity.check_batch(seed, case)
         except AssertionError as e:
             raise AssertionError(f"seed {seed} ({fuzz_parity.describe(*case)}): {e}") from e
 

@@ -130,15 +130,96 @@ def describe(world, cam, renderer, w, h, kw):
     return f"{len(world.shapes):3d} shapes {type(cam).__name__[:5]} {w}x{h} aa{kw['aa']} {r}"
 
 
+def check_case(seed, case):
+    """check_image (default schedule + one pass, against the oracle), then the same frame under a random pass
+    schedule and team-size cap (the wavefront machinery must never change a pixel or a counter)."""
+    from test_gpu_parity import assert_bit_equal, check_image, gpu_render
+    world, cam, renderer, w, h = case[:5]
+    g, st = check_image(world, cam, renderer, w, h, **case[5])
+    if isinstance(renderer, ra.PathTracer):
+        rng = np.random.default_rng(seed ^ 0x5EED)
+        schedule = [(1,), (2, 3), (8,), (5, 7, 11, 13), (48, 64, 96), (200,), (1, 1, 1, 1, 1, 1)][int(rng.integers(0, 7))]
+        team = ["1", "2", "4", "16", "64"][int(rng.integers(0, 5))]
+        old = os.environ.get("RUSTRACER_MAX_TEAM")
+        os.environ["RUSTRACER_MAX_TEAM"] = team
+        try:
+            g2, st2 = gpu_render(world, cam, renderer, w, h, schedule=schedule, **case[5])
+        finally:
+            if old is None:
+                del os.environ["RUSTRACER_MAX_TEAM"]
+            else:
+                os.environ["RUSTRACER_MAX_TEAM"] = old
+        assert_bit_equal(g2.cpu().numpy(), g, f"schedule {schedule} max_team {team}")
+        for k in ("rays", "samples", "diffuse_scatters", "specular_scatters"):
+            assert st2[k] == st[k], (schedule, team, k, st2[k], st[k])
+    return g, st
+
+
+def random_rays(rng, n, max_depth):
+    from rustracer_amd.world import to_rt_ray
+    rays = []
+    for _ in range(n):
+        o = rng.uniform(-8, 8, 3)
+        u = rng.random()
+        if u < 0.15:
+            o = o * float(10 ** rng.uniform(1, 6))         # far origins: the discriminant is mostly rounding
+        d = rng.normal(size=3)
+        if u > 0.9:
+            d = np.zeros(3)
+            d[int(rng.integers(0, 3))] = float(rng.choice([-1, 1]))
+        elif u > 0.88:
+            d = np.zeros(3)
+        kw = {}
+        if rng.random() < 0.3:
+            kw["tmin"] = float(10 ** rng.uniform(-5, 0))
+        if rng.random() < 0.2:
+            kw["tmax"] = float(10 ** rng.uniform(-1, 2))
+        kw["depth"] = int(rng.integers(0, max_depth + 2))
+        rays.append(to_rt_ray(ra.Ray(origin=tuple(o), dir=tuple(d), **kw)))
+    return rays
+
+
+def check_batch(seed, case):
+    """World::ray_intersection and Renderer::solve on a batch of random rays (far origins, axis-parallel and zero
+    directions, tmin / tmax / depth variations) against the oracle."""
+    import ctypes as C
+    import oracle_lib as O
+    from rustracer_amd import _abi
+    from rustracer_amd.world import flatten_world
+    from test_gpu_parity import _hits_equal, assert_bit_equal
+    world, cam, renderer = case[:3]
+    rng = np.random.default_rng(seed ^ 0xBA7C4)
+    md = renderer.max_depth if isinstance(renderer, ra.PathTracer) else 0
+    n = 256 if len(world.shapes) > 96 else 1024
+    rays = random_rays(rng, n, md)
+    flat = flatten_world(world)
+    g = world.ray_intersections(rays)
+    o = O.world_ray_intersection(flat, rays, O.MATH_STRICT)
+    for k, (a, b) in enumerate(zip(g, o)):
+        try:
+            _hits_equal(a, b)
+        except AssertionError as e:
+            raise AssertionError(f"ray {k} ({list(rays[k].origin)}, {list(rays[k].dir)}): gpu {a.hit, a.shape, a.t} oracle {b.hit, b.shape, b.t} {e}") from e
+    pcgs = [(int(rng.integers(0, 2**63)), int(rng.integers(0, 2**62)) * 2 + 1) for _ in rays]
+    r = renderer.flatten()
+    arr = (_abi.rt_ray * len(rays))(*rays)
+    pa = (_abi.rt_pcg * len(rays))(*[_abi.rt_pcg(s, i) for s, i in pcgs])
+    out = np.zeros((len(rays), 3), dtype=np.float32)
+    _abi.check(_abi.lib().rt_renderer_solve(world.device().handle, C.byref(r), arr, pa, len(rays), O.fptr(out)))
+    ref, new = O.renderer_solve(flat, r, rays, pcgs)
+    assert_bit_equal(out, ref, "solve batch")
+    assert [(pa[i].state, pa[i].inc) for i in range(len(rays))] == new, "solve batch: PCG states"
+
+
 def main():
-    from test_gpu_parity import check_image
     first, n = int(sys.argv[1]), int(sys.argv[2])
     bad = 0
     for seed in range(first, first + n):
         case = random_case(seed)
         t0 = time.perf_counter()
         try:
-            _, st = check_image(*case[:5], **case[5])
+            _, st = check_case(seed, case)
+            check_batch(seed, case)
             print(f"seed {seed}: ok   {describe(*case)} rays {st['rays']} ({time.perf_counter() - t0:.1f} s)", flush=True)
         except AssertionError as e:
             bad += 1
