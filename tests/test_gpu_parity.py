@@ -597,7 +597,8 @@ def test_hierarchy_scene_of_ellipsoids_mirrors_and_pigments_path_traced():
 def test_random_scenes():
     """Random scenes (1-400 shapes: LDS and HBM tables, hierarchy, projective matrices, duplicates, every pigment and
     BRDF), cameras, renderers and seeds from tools/fuzz_parity.py, each also under a random pass schedule / team cap
-    and through the batch World::ray_intersection / Renderer::solve calls on adversarial rays; sweeps of 5 350 ordinary and 3 500 extreme seeds ran clean on the MI355X."""
+    and through the batch World::ray_intersection / Renderer::solve calls on adversarial rays, every other one as a
+    multi-frame launch over a random row-tile partition; sweeps of 5 350 ordinary and 3 500 extreme seeds ran clean on the MI355X."""
     import sys
     sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
     import fuzz_parity
@@ -612,6 +613,8 @@ def test_random_scenes():
         try:
             fuzz_parity.check_case(seed, case)
             fuzz_parity.check_batch(seed, case)
+            if seed % 2 == 0:
+                fuzz_parity.check_frames(seed, case)
         except AssertionError as e:
             raise AssertionError(f"seed {seed} ({fuzz_parity.describe(*case)}): {e}") from e
 

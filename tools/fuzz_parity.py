@@ -211,6 +211,54 @@ def check_batch(seed, case):
     assert [(pa[i].state, pa[i].inc) for i in range(len(rays))] == new, "solve batch: PCG states"
 
 
+def check_frames(seed, case):
+    """rt_render_frames: several frames (different cameras) in one launch, a random row-tile partition and pass
+    schedule; every frame's part must equal the oracle's rows of that frame."""
+    import ctypes as C
+    import torch
+    from rustracer_amd import _abi
+    from rustracer_amd.world import flatten_camera
+    from test_gpu_parity import assert_bit_equal, oracle_image
+    world, cam, renderer, w, h, kw = case
+    rng = np.random.default_rng(seed ^ 0xF4A3E5)
+    n_frames = int(rng.choice([1, 2, 3, 4, 9, 12]))
+    if n_frames > 4 and w * h > 600:
+        n_frames = 3
+    cams = [cam]
+    for _ in range(n_frames - 1):
+        t = cam.transformation * ra.rotation_z(float(rng.uniform(-0.5, 0.5))) * ra.translation(tuple(float(x) for x in rng.uniform(-0.3, 0.3, 3)))
+        cams.append(type(cam)(**{**cam.__dict__, "transformation": t}))
+    n_parts = int(rng.choice([1, 2, 3, 5, 8]))
+    tile_rows = int(rng.choice([1, 2, 3, 7, 100]))
+    part = _abi.rt_partition(int(rng.integers(0, n_parts)), n_parts, tile_rows) if n_parts > 1 else None
+    schedule = [(), (0,), (3, 5)][int(rng.integers(0, 3))]
+    lib, dev = _abi.lib(), world.device()
+    r = renderer.flatten()
+    arr = (_abi.rt_camera * n_frames)(*[flatten_camera(c) for c in cams])
+    n_local = lib.rt_partition_pixels(w, h, C.byref(part) if part else None)
+    outs = [torch.full((max(n_local, 1), 3), -7.0, dtype=torch.float32, device="cuda") for _ in cams]
+    ptrs = (C.c_void_p * n_frames)(*[o.data_ptr() for o in outs])
+    st = _abi.rt_stats()
+    dev.set_schedule(schedule)
+    try:
+        _abi.check(lib.rt_render_frames(dev.handle, arr, n_frames, C.byref(r), w, h, kw["init_state"], kw["init_seq"], kw["aa"],
+                                        C.byref(part) if part else None, ptrs, torch.cuda.current_stream().cuda_stream, C.byref(st)))
+    finally:
+        dev.set_schedule(())
+    rows = list(range(h))
+    if part is not None:
+        rows = [y for y in range(h) if (y // tile_rows) % n_parts == part.part]
+    assert n_local == len(rows) * w
+    total_rays = 0
+    for f, c in enumerate(cams):
+        ref, rs = oracle_image(world, c, renderer, w, h, **kw)
+        total_rays += rs["rays"]
+        got = outs[f].cpu().numpy()[:n_local].reshape(len(rows), w, 3)
+        assert_bit_equal(got, ref[rows], f"frame {f} of {n_frames}, part {None if part is None else (part.part, n_parts, tile_rows)}, schedule {schedule}")
+    if part is None:
+        assert st.rays == total_rays, (st.rays, total_rays)
+
+
 def main():
     first, n = int(sys.argv[1]), int(sys.argv[2])
     bad = 0
@@ -220,6 +268,7 @@ def main():
         try:
             _, st = check_case(seed, case)
             check_batch(seed, case)
+            check_frames(seed, case)
             print(f"seed {seed}: ok   {describe(*case)} rays {st['rays']} ({time.perf_counter() - t0:.1f} s)", flush=True)
         except AssertionError as e:
             bad += 1
