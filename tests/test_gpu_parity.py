@@ -598,13 +598,14 @@ def test_random_scenes():
     """Random scenes (1-400 shapes: LDS and HBM tables, hierarchy, projective matrices, duplicates, every pigment and
     BRDF), cameras, renderers and seeds from tools/fuzz_parity.py, each also under a random pass schedule / team cap
     and through the batch World::ray_intersection / Renderer::solve calls on adversarial rays, every other one as a
-    multi-frame launch over a random row-tile partition; sweeps of 5 350 ordinary and 3 500 extreme seeds ran clean on the MI355X."""
+    multi-frame launch over a random row-tile partition; sweeps of 5 350 ordinary and 4 700 extreme seeds ran clean on the MI355X."""
     import sys
     sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
     import fuzz_parity
     # seeds from a million on add extreme transforms (huge, tiny, flat: infinite / NaN matrices) and colours; the listed
     # ones had a plane hit at t = NaN that the hierarchy ordered differently from the linear scan
-    seeds = list(range(1000, 1060)) + list(range(1000000, 1000060)) + [1000076, 1000165, 1000221, 1000347, 1000651]
+    seeds = list(range(1000, 1060)) + list(range(1000000, 1000060)) + [1000076, 1000165, 1000221, 1000347, 1000651] + \
+        list(range(2000000, 2000030))       # ... and from two million on: negative / huge / infinite / NaN colours
     import warnings
     for seed in seeds:
         with warnings.catch_warnings():

@@ -17,9 +17,14 @@ sys.path.insert(0, os.path.join(ROOT, "tests"))
 import rustracer_amd as ra  # noqa: E402
 
 
-def random_pigment(rng, tex, bright=1.0):
+def random_pigment(rng, tex, bright=1.0, nasty=False):
     k = rng.integers(0, 10)
     col = tuple(float(x) * bright for x in rng.uniform(0.0, 1.0, 3))
+    if nasty and rng.random() < 0.1:
+        # colours no renderer should see, but f32 arithmetic defines: negative, huge, infinite, NaN
+        col = tuple(float(rng.choice([-0.5, 0.0, 1e20, 3e38, float("inf"), float("nan"), 1.0, 0.3])) for _ in range(3))
+        if rng.random() < 0.3:
+            return ra.CheckeredPigment(col, (0.2, 0.4, 0.6), int(rng.choice([0, 1, 2**31 - 1])))
     if k < 6:
         return ra.UniformPigment(col)
     if k < 8:
@@ -68,7 +73,8 @@ def random_transform(rng, spread, rmin, rmax, projective=False, nasty=False):
 
 def random_case(seed):
     rng = np.random.default_rng(seed)
-    nasty = seed >= 1_000_000           # seeds from a million on also draw extreme transforms and colours
+    nasty = seed >= 1_000_000           # seeds from a million on also draw extreme transforms and backgrounds,
+    nasty2 = seed >= 2_000_000          # from two million on extreme colours and checker steps as well
     tex = ra.HdrImage(int(rng.integers(1, 9)), int(rng.integers(1, 9)))
     tex.pixels = rng.uniform(0, 1, (tex.height, tex.width, 3)).astype(np.float32)
     size_class = int(rng.integers(0, 4))
@@ -78,8 +84,8 @@ def random_case(seed):
     if rng.random() < 0.7:      # an emissive enclosure, so that paths return light
         world.add(ra.Sphere(ra.scaling((60, 60, 60)), ra.Material(ra.DiffuseBRDF(ra.UniformPigment(ra.BLACK)), random_pigment(rng, tex))))
     while len(world.shapes) < n_shapes:
-        emit = random_pigment(rng, tex, 0.5) if rng.random() < 0.15 else ra.UniformPigment(ra.BLACK)
-        pig = random_pigment(rng, tex)
+        emit = random_pigment(rng, tex, 0.5, nasty2) if rng.random() < 0.15 else ra.UniformPigment(ra.BLACK)
+        pig = random_pigment(rng, tex, 1.0, nasty2)
         brdf = ra.SpecularBRDF(pig) if rng.random() < 0.3 else ra.DiffuseBRDF(pig)
         mat = ra.Material(brdf, emit)
         u = rng.random()
