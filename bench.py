@@ -4,7 +4,7 @@
 A step = one ImageTracer::fire_all_rays pass (one whole frame) with the scene already resident in
 HBM and the image left in HBM.  Steps are issued as launches of B frames (rt_render_frames: the
 frames of a launch share one pixel queue on the GPU; default: the steps dealt evenly over the fewest launches
-of at most 64 frames) over F HIP streams (default 2),
+of at most 128 frames) over F HIP streams (default 1; 2 with several GPUs, for the gather),
 so B*F frames are in flight; every frame is rendered in full, nothing is cached between frames.  N GPUs split EVERY
 frame by row tiles dealt round-robin (strong scaling), one process per GPU, and one RCCL gather
 per launch brings the parts to rank 0, where rt_unpack_parts assembles the images.
@@ -29,12 +29,12 @@ INIT_STATE, INIT_SEQ = 42, 54
 EXPECTED_RAYS = 44180520            # oracle (strict math) ray count of this exact frame; tests/test_gpu_parity.py
 PEAK_FP32_VECTOR_TFLOPS = 157.3     # MI355X_MICROARCH.md: spec, packed FMA counted as 2 flop
 PEAK_STRICT_NOFMA_TFLOPS = 78.6     # same issue rate with unfused mul/add (the reference forbids FMA contraction)
-# HBM bytes per frame of the default configuration, from profiles/r01b_rocprof_default_F2_B16.txt (rocprofv3
-# --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate passes, mean KB per dispatch over 5 dispatches that render
-# 1 + 16 + 3*16 = 65 frames: 15649 and 371850; FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for gfx950):
-# (2*15649 + 371850) KB * 5 / 65 = 31 MB.  The algorithmic minimum is the 24.9 MB image (12-byte pixel stores
-# fill cache lines partially); the path is VALU-bound, not HBM-bound.
-TRAFFIC_BYTES_PER_FRAME = (2 * 15649 + 371850) * 1000 * 5 / 65
+# HBM bytes per frame of the default configuration, from profiles/r01c_rocprof_default.txt (rocprofv3
+# --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate passes, mean KB per dispatch over 4 dispatches that render
+# 1 + 24 + 2*120 = 265 frames: 191 and 1726500; FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for gfx950):
+# (2*191 + 1726500) KB * 4 / 265 = 26.1 MB.  The algorithmic minimum is the 24.9 MB image (12-byte pixel stores
+# fill cache lines partially; the scene is read once per block into LDS); the path is VALU-bound, not HBM-bound.
+TRAFFIC_BYTES_PER_FRAME = (2 * 191 + 1726500) * 1000 * 4 / 265
 
 
 def partition_rows(height, part, n_parts, tile_rows):
@@ -55,12 +55,15 @@ def cpu_baseline(flat, cam, rr, threads):
     """The CPU checker (oracle/, the reference's algorithm restated) on this box's host cores."""
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import oracle_lib as O
+    reps = 3
     t0 = time.perf_counter()
-    _, st = O.fire_all_rays(flat, cam, rr, WIDTH, HEIGHT, INIT_STATE, INIT_SEQ, AA, math_mode=O.MATH_LIBM,
-                            n_threads=threads)
-    dt = time.perf_counter() - t0
+    for _ in range(reps):
+        _, st = O.fire_all_rays(flat, cam, rr, WIDTH, HEIGHT, INIT_STATE, INIT_SEQ, AA, math_mode=O.MATH_LIBM,
+                                n_threads=threads)
+    dt = (time.perf_counter() - t0) / reps
     return {"value": WIDTH * HEIGHT * AA * AA / dt, "unit": "path samples/s", "cores": threads, "kind": "port",
-            "sample": f"the full {WIDTH}x{HEIGHT} frame once ({st['rays']} rays, {dt:.2f} s wall incl. serial all_rays)",
+            "sample": f"the full {WIDTH}x{HEIGHT} frame {reps} times ({st['rays']} rays each, {dt:.2f} s wall per frame "
+                      "incl. serial all_rays)",
             "rays_per_s": st["rays"] / dt}
 
 
@@ -70,14 +73,15 @@ def main():
     ap.add_argument("--steps", type=int, default=240)
     ap.add_argument("--warmup", type=int, default=24)
     ap.add_argument("--tile-rows", type=int, default=1)
-    ap.add_argument("--inflight", type=int, default=2, help="launches in flight on separate HIP streams (1..4)")
+    ap.add_argument("--inflight", type=int, default=0,
+                    help="launches in flight on separate HIP streams (1..4; default 1, with several GPUs 2)")
     ap.add_argument("--frames-per-launch", type=int, default=0,
                     help="frames rendered by one rt_render_frames launch (default: the steps dealt evenly over the "
-                         "fewest launches of at most 64 frames)")
+                         "fewest launches of at most 128 frames)")
     ap.add_argument("--schedule", choices=["auto", "passes", "onepass"], default="auto",
                     help="rt_scene_set_schedule: 'passes' = short passes (lowest single-frame latency), 'onepass' = one "
                          "pass per launch (best throughput with many frames in flight); auto = onepass unless "
-                         "--inflight 1 --frames-per-launch 1")
+                         "--frames-per-launch 1 on one stream")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--dist-backend", choices=["nccl", "gloo"], default="nccl",
                     help="gloo: rehearse the N > 1 path on a box with fewer GPUs than ranks (parts staged through host memory)")
@@ -112,17 +116,20 @@ def main():
     cam = flatten_camera(demo_camera(WIDTH, HEIGHT))
     rr = ra.PathTracer(scene, ra.BLACK, NUM_OF_RAYS, MAX_DEPTH, RR_LIMIT).flatten()
     dev = scene.device()          # World resident in HBM before the timed region
-    F = max(1, min(args.inflight, 4))
+    # one stream: a launch of this size fills the GPU by itself, and launches that share it run slower than one
+    # after the other (measured: 240 steps 0.78 vs 0.79 ms/frame, 100 steps 0.79 vs 0.84); with several GPUs a
+    # second stream lets the gather of one launch run beside the next launch
+    F = max(1, min(args.inflight, 4)) if args.inflight else (2 if world_size > 1 else 1)
     if args.frames_per_launch:
-        B = max(1, min(args.frames_per_launch, 64))
+        B = max(1, min(args.frames_per_launch, 512))
     else:
-        # the fewest launches of at most 64 frames, the steps dealt evenly over them: every launch ends with one
-        # drain of long pixels, and launches in flight on different streams drain together.  With several GPUs
-        # at least 4 launches, so that the gather of one overlaps the render of the next.
-        n_l = (args.steps + 63) // 64
+        # the fewest launches of at most 128 frames, the steps dealt evenly over them: every launch ends with one
+        # drain of long pixels (measured, 240 steps: launches of 60 / 120 frames 0.78 / 0.75 ms/frame).  With
+        # several GPUs at least 4 launches, so that the gather of one can overlap the render of the next.
+        n_l = (args.steps + 127) // 128
         if world_size > 1:
             n_l = max(n_l, min(4, args.steps))
-        B = max(1, min((args.steps + n_l - 1) // n_l, 64))
+        B = max(1, min((args.steps + n_l - 1) // n_l, 128))
     onepass = args.schedule == "onepass" or (args.schedule == "auto" and (F > 1 or B > 1))
     dev.set_schedule((0,) if onepass else ())
 

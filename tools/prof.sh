@@ -4,7 +4,9 @@ cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
 OUT=$R/gpurun_out/prof
 rm -rf $OUT && mkdir -p $OUT
-ARGS="$R/bench.py --steps ${STEPS:-48} --warmup ${WARMUP:-16} --no-cpu-baseline --frames-per-launch ${FRAMES:-16} ${BENCH_ARGS:-}"
+# default: bench.py's own defaults (the command the driver runs), minus the CPU baseline
+ARGS="$R/bench.py --no-cpu-baseline ${BENCH_ARGS:-}"
+export PROF_CMD="python3 bench.py --no-cpu-baseline ${BENCH_ARGS:-}"
 timeout -s KILL 170 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- python3 $ARGS > $OUT/trace.log 2>&1 || exit 1
 timeout -s KILL 170 rocprofv3 --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_SMEM SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_BRANCH --output-format csv -d $OUT/pmc1 -- python3 $ARGS > $OUT/pmc1.log 2>&1 || exit 1
 timeout -s KILL 170 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_THREAD_CYCLES_VALU SQ_INST_CYCLES_SALU --output-format csv -d $OUT/pmc2 -- python3 $ARGS > $OUT/pmc2.log 2>&1 || exit 1

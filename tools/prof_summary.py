@@ -1,7 +1,7 @@
 """Condense gpurun_out/prof (rocprofv3 csv) into a text summary for profiles/."""
-import csv, glob, collections, sys
+import csv, glob, collections, os, sys
 root = sys.argv[1] if len(sys.argv) > 1 else "gpurun_out/prof"
-print("== rocprofv3 --kernel-trace --stats -- python3 bench.py --steps 48 --warmup 12 --no-cpu-baseline ==")
+print("== rocprofv3 --kernel-trace --stats -- " + os.environ.get("PROF_CMD", "python3 bench.py --no-cpu-baseline") + " ==")
 for f in glob.glob(root + "/trace/*/*_kernel_stats.csv"):
     for r in csv.DictReader(open(f)):
         print(f"{r['Name'][:110]:110s} calls={r['Calls']:>4s} avg_ns={float(r['AverageNs']):12.0f} pct={r['Percentage']}")
