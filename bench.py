@@ -6,8 +6,11 @@ HBM and the image left in HBM.  Steps are issued as launches of B frames (rt_ren
 frames of a launch share one pixel queue on the GPU; default: the steps dealt evenly over the fewest launches
 of at most 128 frames) over F HIP streams (default 1; 2 with several GPUs, for the gather),
 so B*F frames are in flight; every frame is rendered in full, nothing is cached between frames.  N GPUs split EVERY
-frame by row tiles dealt round-robin (strong scaling), one process per GPU, and one RCCL gather
-per launch brings the parts to rank 0, where rt_unpack_parts assembles the images.
+frame by row tiles dealt round-robin (strong scaling), one process per GPU; every rank pushes its part of a
+launch into rank 0's buffers (mapped through HIP IPC handles) with a device-to-device copy that runs beside the next
+launch's render, a CPU-side barrier per launch tells rank 0 when the parts are complete, and rt_unpack_parts
+assembles the images there (--gather rccl, also the fallback when the handles cannot be exchanged: one RCCL gather
+per launch instead).
 
   python bench.py --gpus 1 --steps K --warmup W
   python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
@@ -85,6 +88,11 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--dist-backend", choices=["nccl", "gloo"], default="nccl",
                     help="gloo: rehearse the N > 1 path on a box with fewer GPUs than ranks (parts staged through host memory)")
+    ap.add_argument("--gather", choices=["rccl", "p2p"], default="p2p",
+                    help="N > 1: how the parts reach rank 0.  rccl: one gather collective per launch.  p2p: rank 0 shares "
+                         "its buffers through HIP IPC handles and every rank pushes its part with a device-to-device copy "
+                         "(copy engine: runs beside the next launch's render, which an RCCL kernel cannot), with a "
+                         "CPU-side barrier per launch; falls back to rccl if the handles cannot be exchanged")
     ap.add_argument("--verify", action="store_true",
                     help="after the run, rank 0 compares every assembled image with a whole-frame render, bit for bit")
     args = ap.parse_args()
@@ -142,12 +150,46 @@ def main():
     # for N > 1, gather(l) overlaps render(l+1)).
     streams = [torch.cuda.Stream() for _ in range(F)]
     cams = (_abi.rt_camera * B)(*([cam] * B))
-    images = [torch.zeros((B, HEIGHT, WIDTH, 3), dtype=torch.float32, device="cuda") for _ in range(F)]
+    # p2p gather: two more sets of gathered / image buffers than launches in flight, so that a part pushed by launch l
+    # lands in a buffer whose previous reader (rank 0's unpack of launch l - NB) is known to have finished
+    cpu_group, remote = None, None
+    NB = F
     bufs = gathered = None
     if world_size > 1:
         bufs = [torch.zeros((B, stride, 3), dtype=torch.float32, device="cuda") for _ in range(F)]
-        if rank == 0:
+        if args.gather == "p2p":
+            from torch.multiprocessing.reductions import reduce_tensor
+            NB = F + 2
+            cpu_group = dist.new_group(backend="gloo") if args.dist_backend == "nccl" else dist.group.WORLD
+            ok, box = 1, [None]
+            if rank == 0:
+                try:
+                    gathered = [torch.zeros((world_size, B, stride, 3), dtype=torch.float32, device="cuda") for _ in range(NB)]
+                    box[0] = [reduce_tensor(t) for t in gathered]
+                except Exception as e:   # noqa: BLE001 - any failure means: use the collective
+                    print(f"p2p gather unavailable on rank 0: {e}", file=sys.stderr)
+                    box[0], ok = None, 0
+            dist.broadcast_object_list(box, src=0, group=cpu_group)
+            if rank == 0:
+                remote = gathered
+            elif box[0] is None:
+                ok = 0
+            else:
+                try:
+                    remote = [fn(*a) for fn, a in box[0]]     # rank 0's buffers mapped into this process
+                    remote[0][rank, 0, :1].copy_(bufs[0][0, :1])  # a first write through the mapping, checked here
+                    torch.cuda.synchronize()
+                except Exception as e:   # noqa: BLE001
+                    print(f"p2p gather unavailable on rank {rank}: {e}", file=sys.stderr)
+                    ok = 0
+            flag = torch.tensor([ok], dtype=torch.int32)
+            dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=cpu_group)
+            if int(flag[0]) == 0:
+                cpu_group, remote, gathered, NB = None, None, None, F
+        if remote is None and rank == 0:
             gathered = [torch.zeros((world_size, B, stride, 3), dtype=torch.float32, device="cuda") for _ in range(F)]
+    images = [torch.zeros((B, HEIGHT, WIDTH, 3), dtype=torch.float32, device="cuda") for _ in range(NB)]
+    copy_done, unpack_done = {}, {}
 
     def out_ptrs(slot, n):
         t = bufs[slot] if world_size > 1 else images[slot]
@@ -163,7 +205,13 @@ def main():
                                             C.byref(part), out_ptrs(slot, n), st.cuda_stream, stats))
             if ev:
                 ev[1].record(st)
-            if world_size > 1:
+            if remote is not None:
+                # push this rank's part into rank 0's buffer (device-to-device copy on this stream); complete() does
+                # the rest once every rank's copy has landed
+                remote[l % NB][rank, :n].copy_(bufs[slot][:n], non_blocking=True)
+                copy_done[l] = torch.cuda.Event()
+                copy_done[l].record(st)
+            elif world_size > 1:
                 # the collective runs on RCCL's stream after st's render; work.wait() makes st (not the
                 # host) wait for it, so the slot's buffers are free again when st reaches its next launch
                 if args.dist_backend == "gloo":
@@ -183,15 +231,38 @@ def main():
                                                        args.tile_rows, WIDTH, HEIGHT, images[slot][b].data_ptr(),
                                                        st.cuda_stream))
 
+    def complete(l, n):
+        """p2p gather: launch l's parts are in rank 0's buffer l % NB once every rank's copy has finished (CPU barrier);
+        rank 0 then assembles the images.  Rank 0 enters the barrier of launch l only after its unpack of launch l - 2
+        has finished (its kernels run in the gaps the render leaves), which is what lets launch l + F overwrite that
+        buffer."""
+        copy_done.pop(l).synchronize()
+        if rank == 0 and (l - 2) in unpack_done:
+            unpack_done.pop(l - 2).synchronize()
+        dist.barrier(group=cpu_group)
+        if rank == 0:
+            st = streams[l % F]
+            for b in range(n):
+                _abi.check(lib.rt_unpack_parts(gathered[l % NB][0, b].data_ptr(), B * stride, world_size, args.tile_rows,
+                                               WIDTH, HEIGHT, images[l % NB][b].data_ptr(), st.cuda_stream))
+            unpack_done[l] = torch.cuda.Event()
+            unpack_done[l].record(st)
+
     def run(steps, events=None):
-        l = 0
+        sizes = []
         done = 0
         while done < steps:
-            n = min(B, steps - done)
+            sizes.append(min(B, steps - done))
+            done += sizes[-1]
+        for l, n in enumerate(sizes):
+            if remote is not None and l >= F:
+                complete(l - F, sizes[l - F])
             launch(l, n, events[l] if events is not None else None)
-            done += n
-            l += 1
-        return l
+        if remote is not None:
+            for l in range(max(0, len(sizes) - F), len(sizes)):
+                complete(l, sizes[l])
+            unpack_done.clear()
+        return len(sizes)
 
     def sync_all():
         torch.cuda.synchronize()
@@ -202,6 +273,9 @@ def main():
     # one instrumented single-frame launch: ray counters of this rank's part (deterministic, same every step)
     st = _abi.rt_stats()
     launch(0, 1, stats=C.byref(st))
+    if remote is not None:
+        complete(0, 1)
+        unpack_done.clear()
     my_rays = st.rays
     if world_size == 1 and my_rays != EXPECTED_RAYS and not os.environ.get("RUSTRACER_BENCH_ABLATION"):
         raise SystemExit(f"ray counter {my_rays} != {EXPECTED_RAYS} (oracle, World::ray_intersection calls of this frame)")
@@ -238,12 +312,15 @@ def main():
                                  ref.data_ptr(), torch.cuda.current_stream().cuda_stream, None))
         torch.cuda.synchronize()
         n_last = args.steps - (n_launches - 1) * B     # frames of the last launch
-        for slot in range(min(F, n_launches)):
-            n_chk = n_last if slot == (n_launches - 1) % F else B
+        checked = 0
+        for l in range(max(0, n_launches - NB), n_launches):   # the launches whose images are still in a buffer
+            n_chk = n_last if l == n_launches - 1 else B
             for b in range(n_chk):
-                if not torch.equal(images[slot][b].view(torch.int32), ref.view(torch.int32)):
-                    raise SystemExit(f"verify: image {b} of slot {slot} differs from the whole-frame render")
-        print(f"verify ok: {min(F, n_launches)} slots x up to {B} images bit-identical to a whole-frame render", file=sys.stderr)
+                if not torch.equal(images[l % NB][b].view(torch.int32), ref.view(torch.int32)):
+                    raise SystemExit(f"verify: image {b} of launch {l} differs from the whole-frame render")
+            checked += n_chk
+        print(f"verify ok: {checked} images of the last {min(NB, n_launches)} launches bit-identical to a whole-frame render"
+              + (" (p2p gather)" if remote is not None else ""), file=sys.stderr)
 
     if rank == 0:
         samples_per_step = WIDTH * HEIGHT * AA * AA
@@ -261,7 +338,8 @@ def main():
             "config": {"workload": f"examples/demo.yml scene (4 shapes), pathtracer n={NUM_OF_RAYS} d={MAX_DEPTH} "
                                    f"rr={RR_LIMIT}, {WIDTH}x{HEIGHT}, aa={AA}, seeds {INIT_STATE}/{INIT_SEQ}",
                        "parallelism": (f"row tiles ({args.tile_rows} rows) of every frame round-robin over {world_size} "
-                                       "GPU(s), RCCL gather to rank 0") if world_size > 1 else "1 GPU, whole frames",
+                                       "GPU(s), " + ("peer-copy gather (HIP IPC)" if remote is not None else "RCCL gather") + " to rank 0")
+                                      if world_size > 1 else "1 GPU, whole frames",
                        "frames_per_launch": B, "launches_in_flight": F,
                        "schedule": "onepass" if onepass else "passes",
                        "rays_per_frame": total_rays, "rays_per_s": total_rays * args.steps / dt},
@@ -278,6 +356,12 @@ def main():
             out["cpu_baseline"] = cpu_baseline(flat, cam, rr, threads)
         print(json.dumps(out), flush=True)
     if world_size > 1:
+        if remote is not None:
+            # consumers let go of rank 0's buffers before rank 0 frees them
+            if rank != 0:
+                remote = None
+            torch.cuda.synchronize()
+            dist.barrier(group=cpu_group)
         dist.destroy_process_group()
 
 
