@@ -180,6 +180,21 @@ int rt_render_frames(const rt_scene* scene, const rt_camera* cameras, uint32_t n
                      const rt_partition* part /* NULL = whole image */,
                      float* const* d_out_rgb, void* stream, rt_stats* stats /* nullable */);
 
+/* rt_render for callers that cannot allocate (code under HIP graph capture, tight serving loops, harnesses
+ * that forbid hipMalloc).  It has no counterpart in the reference.  Same arguments, same pixels as rt_render,
+ * but the call allocates nothing on host or device: the launch's control block (queue head, ray counters) and, for
+ * recursions too deep for LDS, the recursion stack live in a file-scope device array of RT_NOALLOC_SCRATCH_BYTES
+ * that every GPU the library runs on holds until the process ends (its address is resolved per device by rt_init,
+ * or by the first call on a device).  Always one pass, one lane per pixel; no stats.  max_depth beyond what the
+ * scratch holds for one 256-lane block (RT_NOALLOC_MAX_DEPTH) is rejected with an error.  Calls on one GPU share
+ * that GPU's array: calls that overlap on one GPU (different streams) race; calls on one stream are ordered. */
+#define RT_NOALLOC_SCRATCH_BYTES (8u * 1024u * 1024u + 4096u)
+#define RT_NOALLOC_MAX_DEPTH 513u
+int rt_render_noalloc(const rt_scene* scene, const rt_camera* camera, const rt_renderer* renderer,
+                      uint32_t width, uint32_t height, uint64_t init_state, uint64_t init_seq,
+                      uint32_t antialiasing_level, const rt_partition* part /* NULL = whole image */,
+                      float* d_out_rgb, void* stream);
+
 /* Inverse of the row-tile partition: scatter `n_parts` gathered part buffers (each padded to
  * `part_stride_pixels` pixels, DEVICE memory) into the full image d_image_rgb (DEVICE). */
 int rt_unpack_parts(const float* d_parts_rgb, uint64_t part_stride_pixels, uint32_t n_parts,

@@ -16,6 +16,8 @@ RT_PIGMENT_UNIFORM, RT_PIGMENT_CHECKERED, RT_PIGMENT_IMAGE = 0, 1, 2
 RT_BRDF_DIFFUSE, RT_BRDF_SPECULAR = 0, 1
 RT_CAMERA_ORTHOGONAL, RT_CAMERA_PERSPECTIVE = 0, 1
 RT_ALGO_ONOFF, RT_ALGO_FLAT, RT_ALGO_PATHTRACER, RT_ALGO_DUMMY = 0, 1, 2, 3
+RT_NOALLOC_SCRATCH_BYTES = 8 * 1024 * 1024 + 4096
+RT_NOALLOC_MAX_DEPTH = 513
 
 
 class rt_shape(C.Structure):
@@ -91,6 +93,9 @@ SIGNATURES = {
     "rt_render_frames": (C.c_int, [C.c_void_p, P(rt_camera), C.c_uint32, P(rt_renderer), C.c_uint32, C.c_uint32,
                                    C.c_uint64, C.c_uint64, C.c_uint32, P(rt_partition), P(C.c_void_p),
                                    C.c_void_p, P(rt_stats)]),
+    "rt_render_noalloc": (C.c_int, [C.c_void_p, P(rt_camera), P(rt_renderer), C.c_uint32, C.c_uint32,
+                                    C.c_uint64, C.c_uint64, C.c_uint32, P(rt_partition), C.c_void_p,
+                                    C.c_void_p]),
     "rt_unpack_parts": (C.c_int, [C.c_void_p, C.c_uint64, C.c_uint32, C.c_uint32, C.c_uint32,
                                   C.c_uint32, C.c_void_p, C.c_void_p]),
     "rt_fire_all_rays": (C.c_int, [P(rt_shape), C.c_uint32, P(rt_material), C.c_uint32,
