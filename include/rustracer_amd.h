@@ -108,10 +108,15 @@ typedef struct rt_pcg {
 } rt_pcg;
 
 /* Which rows of the image this call renders: row tiles of `tile_rows` rows dealt round-robin,
- * tile j of the image belongs to part (j % n_parts).  One part per GPU; {0,1,any} = whole image.
- * (Replaces rayon's par_iter over pixels, src/imagetracer.rs:112-123.) */
+ * tile j of the image belongs to part (j % n_parts).  One part per GPU; {0,1,any,0} = whole image.
+ * (Replaces rayon's par_iter over pixels, src/imagetracer.rs:112-123.)
+ * rotate != 0 (multi-frame launches): frame f of the launch renders part (part + f) % n_parts instead, so over
+ * n_parts consecutive frames every GPU renders every part once.  With tile_rows = height / n_parts a part is one
+ * contiguous block of rows that lands in the final image with a plain copy (no rt_unpack_parts) and the rotation
+ * balances the blocks' unequal costs over the frames.  Needs equal parts: height % (tile_rows * n_parts) == 0. */
 typedef struct rt_partition {
     uint32_t part, n_parts, tile_rows;
+    uint32_t rotate;
 } rt_partition;
 
 /* Counters of one render call. */
@@ -203,13 +208,24 @@ int rt_unpack_parts(const float* d_parts_rgb, uint64_t part_stride_pixels, uint3
 
 /* Blocking one-shot with host buffers: exactly ImageTracer::new + fire_all_rays +
  * HdrImage::set_pixels (src/imagetracer.rs:40, :105-125; src/hdrimage.rs:86-96).
- * out_rgb: width*height*3 floats, HdrImage order (row 0 = top), fully overwritten. */
+ * out_rgb: width*height*3 floats, HdrImage order (row 0 = top), fully overwritten.
+ * Multi-GPU fan-out is internal: the rows are dealt round-robin over the GPUs in use (RUSTRACER_DEVICES = a list of
+ * device indices, or RUSTRACER_NUM_DEVICES = a count; default: one GPU per 2^21 samples of the frame, the current device first), every
+ * GPU renders its part and copies it to the host over its own link, host threads place the rows in out_rgb.
+ * Between calls the library keeps, per GPU, the uploaded World (reused while the tables' contents are unchanged),
+ * the device image and a pinned staging buffer.  stats->kernel_ms is the longest GPU's. */
 int rt_fire_all_rays(const rt_shape* shapes, uint32_t n_shapes,
                      const rt_material* materials, uint32_t n_materials,
                      const rt_texture* textures, uint32_t n_textures,
                      const rt_camera* camera, const rt_renderer* renderer,
                      uint32_t width, uint32_t height, uint64_t init_state, uint64_t init_seq,
                      uint32_t antialiasing_level, float* out_rgb, rt_stats* stats /* nullable */);
+
+/* Which GPUs the last rt_fire_all_rays of this thread used and how long each one's render kernels ran (the
+ * fan-out is internal to that call; no counterpart in the reference, where rayon spreads the pixels over the cores,
+ * src/imagetracer.rs:112-123).  Fills up to `cap` entries of devices[] / kernel_ms[] (either may be NULL) and
+ * returns the number of parts of that call (one per device in use). */
+uint32_t rt_last_fire_devices(int32_t* devices, double* kernel_ms, uint32_t cap);
 
 /* Replaces World::ray_intersection (src/world.rs:32-50) for a batch of host rays. */
 int rt_world_ray_intersection(const rt_scene* scene, const rt_ray* rays, uint64_t n_rays,

@@ -92,8 +92,10 @@ struct PassParams {
     uint64_t master_state0, master_inc;   // Pcg::new(init_state, init_seq)
     uint64_t pix_mult[32], pix_plus[32];  // master jump by 2^i pixels (2*aa^2+1 draws each)
     uint64_t seq_mult, seq_plus;          // master jump by 2*aa^2 draws (to the pixel's seq draw)
-    // partition (row tiles dealt round-robin)
+    // partition (row tiles dealt round-robin); part_rotate: frame f of the launch renders part (part + f) % n_parts
     uint32_t part, n_parts, tile_rows;
+    uint32_t part_rotate;
+    uint32_t mg_parts[3];            // magic division by n_parts
     // exact u32 division by invariant divisors (Granlund-Montgomery, host: magic_u32): width, n_per_frame, tile_rows
     uint32_t mg_width[3], mg_npf[3], mg_tile[3];
     uint32_t n_items;                // n_frames * (pixels of this part) / solve items
@@ -203,7 +205,12 @@ __device__ __forceinline__ void local_to_global(ColdParams P, uint32_t item, uin
     const uint32_t lrow = div_magic(lq, P->mg_width[0], P->mg_width[1], P->mg_width[2]);
     gcol = lq - lrow * width;
     const uint32_t tile = (tile_rows > 1u) ? div_magic(lrow, P->mg_tile[0], P->mg_tile[1], P->mg_tile[2]) : lrow;
-    grow = (tile * P->n_parts + P->part) * tile_rows + (lrow - tile * tile_rows);
+    uint32_t part = P->part;
+    if (P->part_rotate != 0u) {
+        const uint32_t x = part + frame;
+        part = x - div_magic(x, P->mg_parts[0], P->mg_parts[1], P->mg_parts[2]) * P->n_parts;
+    }
+    grow = (tile * P->n_parts + part) * tile_rows + (lrow - tile * tile_rows);
 }
 
 // ImageTracer::fire_ray + Camera::fire_ray for sample `samp` of pixel (grow, gcol)

@@ -1,0 +1,167 @@
+"""GPU parity at BASELINE.json's own parameters (configs 2-5), the GPU-vs-libm outlier bound on the headline frame,
+and the internal multi-GPU fan-out of the drop-in call.
+
+C2 runs at its full size.  C4 / C5 use the configs' renderer parameters (pathtracer n=10, depth 3, roulette 3;
+C5 with 4x4 antialiasing) at the largest resolution the CPU oracle -- a literal linear scan over 228 / 10 002
+shapes per ray -- finishes in about a minute on the GPU box's 16 host threads.  Bar: bit-exact against the
+strict-math oracle, every counter equal.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+import pytest
+
+import oracle_lib as O
+import rustracer_amd as ra
+from rustracer_amd import _abi
+from rustracer_amd.scenes import (demo_camera, demo_world, flake_camera, flake_world, random_spheres_camera,
+                                  random_spheres_world)
+from rustracer_amd.world import flatten_camera, flatten_world
+
+from test_gpu_parity import COUNTERS, assert_bit_equal, gpu_image, gpu_render
+
+pytestmark = pytest.mark.gpu
+
+THREADS = int(os.environ.get("OMP_NUM_THREADS", "0")) or 8
+
+
+def oracle(world, cam, renderer, w, h, aa=1, mode=O.MATH_STRICT):
+    return O.fire_all_rays(flatten_world(world), flatten_camera(cam), renderer.flatten(), w, h, 42, 54, aa,
+                           math_mode=mode, n_threads=THREADS)
+
+
+def test_c2_flat_1280x960_aa4_full_size_bit_exact():
+    """BASELINE config 2 as quoted: demo scene, flat renderer, 1280x960, 4x4 antialiasing."""
+    w, h, aa = 1280, 960, 4
+    world = demo_world()
+    cam, rr = demo_camera(w, h), ra.FlatRenderer(world, ra.BLACK)
+    ref, rs = oracle(world, cam, rr, w, h, aa)
+    g, gs = gpu_image(world, cam, rr, w, h, aa=aa)
+    assert_bit_equal(g, ref, "C2 full size")
+    assert rs["rays"] == w * h * aa * aa
+    for k in COUNTERS:
+        assert gs[k] == rs[k], k
+
+
+def test_c4_flake_textured_at_the_configs_renderer_parameters():
+    """BASELINE config 4: sphere-flake with checkered + image pigments, pathtracer n=10 d=3 rr=3 (1 110 rays per pixel)."""
+    w, h = 320, 180
+    world = flake_world(True)
+    cam, rr = flake_camera(w, h), ra.PathTracer(world, ra.BLACK, 10, 3, 3)
+    ref, rs = oracle(world, cam, rr, w, h)
+    for schedule in [(), (0,)]:
+        g, gs = gpu_render(world, cam, rr, w, h, schedule=schedule)
+        assert_bit_equal(g.cpu().numpy(), ref, f"C4 n=10 d=3 rr=3 schedule={schedule}")
+        for k in COUNTERS:
+            assert gs[k] == rs[k], (schedule, k, gs[k], rs[k])
+
+
+def test_c5_random_spheres_aa4_at_the_configs_renderer_parameters():
+    """BASELINE config 5: 10 002 shapes, pathtracer n=10 d=3 rr=3, 16 samples per pixel (through the hierarchy)."""
+    w, h, aa = 32, 18, 4
+    world = random_spheres_world(10000)
+    cam, rr = random_spheres_camera(w, h), ra.PathTracer(world, ra.BLACK, 10, 3, 3)
+    ref, rs = oracle(world, cam, rr, w, h, aa)
+    g, gs = gpu_render(world, cam, rr, w, h, aa=aa)
+    assert_bit_equal(g.cpu().numpy(), ref, "C5 n=10 d=3 rr=3 aa=4")
+    for k in COUNTERS:
+        assert gs[k] == rs[k], (k, gs[k], rs[k])
+
+
+def libm_outliers(gpu_img, libm_img):
+    """Pixels whose radiance differs from the libm-mode oracle by more than 1e-4 relative (north_star's tolerance)."""
+    g, o = np.asarray(gpu_img, dtype=np.float64), np.asarray(libm_img, dtype=np.float64)
+    tol = 1e-4 * np.maximum(np.abs(g), np.abs(o)) + 1e-9
+    bad = (np.abs(g - o) > tol).any(axis=-1)
+    return int(bad.sum()), bad.size
+
+
+def test_headline_frame_against_the_libm_oracle_outlier_fraction():
+    """The reference computes sin/cos/atan2/acos with the platform libm (src/material.rs:180, src/shape.rs:102-103),
+    whose last ulp Cargo.lock does not pin.  Against THIS box's glibc: every pixel within 1e-4 relative, except those
+    where a last-ulp difference flips a discrete decision (hit/miss, roulette) and re-routes the pixel's PCG stream;
+    those are counted, never hidden, and must stay a handful."""
+    w, h = 1920, 1080
+    world = demo_world()
+    cam, rr = demo_camera(w, h), ra.PathTracer(world, ra.BLACK, 10, 3, 3)
+    libm, ls = oracle(world, cam, rr, w, h, mode=O.MATH_LIBM)
+    g, gs = gpu_render(world, cam, rr, w, h, schedule=(0,))
+    n_bad, n = libm_outliers(g.cpu().numpy(), libm)
+    frac = n_bad / n
+    print(f"headline frame vs libm oracle: {n_bad} of {n} pixels beyond 1e-4 relative ({frac:.2e}); rays {gs['rays']} vs {ls['rays']}")
+    assert frac <= 2e-5, (n_bad, n)                       # measured: a handful of 2 073 600
+    assert abs(gs["rays"] - ls["rays"]) <= 2000, (gs["rays"], ls["rays"])
+
+
+def test_fire_all_rays_fans_out_over_the_listed_devices(monkeypatch):
+    """The drop-in call's internal fan-out, rehearsed on one GPU by listing device 0 several times: N parts (row tiles
+    dealt round-robin), each with its own scene copy, stream and staging buffer, must give the whole frame bit for bit."""
+    lib = _abi.lib()
+    w, h = 200, 113
+    world = demo_world()
+    cam, rr = demo_camera(w, h), ra.PathTracer(world, ra.BLACK, 10, 3, 3)
+    ref, rs = oracle(world, cam, rr, w, h)
+    for devices, n_parts in (("0,0,0", 3), ("0", 1), ("0,0,0,0,0,0,0,0", 8)):
+        monkeypatch.setenv("RUSTRACER_DEVICES", devices)
+        g, gs = gpu_image(world, cam, rr, w, h)
+        assert_bit_equal(g, ref, f"fan-out {devices}")
+        for k in COUNTERS:
+            assert gs[k] == rs[k], (devices, k, gs[k], rs[k])
+        ms = (C.c_double * 16)()
+        dv = (C.c_int32 * 16)()
+        assert lib.rt_last_fire_devices(dv, ms, 16) == n_parts
+        assert all(dv[i] == 0 for i in range(n_parts)) and all(ms[i] > 0 for i in range(n_parts))
+    # another World through the same cached contexts, then the first one again (aa 2, flat: the image kernel)
+    monkeypatch.setenv("RUSTRACER_DEVICES", "0,0")
+    other = flake_world(True)
+    for wd, cm, r2, aa in ((other, flake_camera(64, 36), ra.FlatRenderer(other, ra.BLACK), 2), (world, cam, rr, 1)):
+        ww, hh = (64, 36) if wd is other else (w, h)
+        g, gs = gpu_image(wd, cm, r2, ww, hh, aa=aa)
+        o, os_ = oracle(wd, cm, r2, ww, hh, aa)
+        assert_bit_equal(g, o, "fan-out after a scene change")
+        assert gs["rays"] == os_["rays"]
+    monkeypatch.delenv("RUSTRACER_DEVICES")
+    monkeypatch.setenv("RUSTRACER_NUM_DEVICES", "7")       # more devices than the box has
+    out = np.zeros((4, 4, 3), dtype=np.float32)
+    st = _abi.rt_stats()
+    flat = flatten_world(world)
+    c4, r4 = flatten_camera(demo_camera(4, 4)), rr.flatten()
+    rc = lib.rt_fire_all_rays(*flat.args(), C.byref(c4), C.byref(r4), 4, 4, 42, 54, 1, O.fptr(out), C.byref(st))
+    import torch
+    if torch.cuda.device_count() < 7:
+        assert rc != 0 and b"RUSTRACER_NUM_DEVICES" in lib.rt_last_error()
+
+
+def test_rotating_row_blocks_land_in_place_without_unpack():
+    """rt_partition.rotate: frame f of a launch renders part (part + f) % n_parts; with tile_rows = height / n_parts
+    every part is one contiguous block of rows, written straight to its place in the frame's final image."""
+    import torch
+    lib = _abi.lib()
+    w, h, n_parts, n_frames = 96, 60, 4, 6
+    world = demo_world()
+    rr = ra.PathTracer(world, ra.BLACK, 10, 3, 3)
+    cams = [demo_camera(w, h, angle_deg=7.0 * f) for f in range(n_frames)]        # an animation: every frame differs
+    refs = [oracle(world, c, rr, w, h)[0] for c in cams]
+    block = h // n_parts
+    images = torch.full((n_frames, h, w, 3), float("nan"), dtype=torch.float32, device="cuda")
+    carr = (_abi.rt_camera * n_frames)(*[flatten_camera(c) for c in cams])
+    r = rr.flatten()
+    total_rays = 0
+    for p in range(n_parts):
+        part = _abi.rt_partition(p, n_parts, block, 1)
+        # frame f's block (p + f) % n_parts, in place in the frame's image
+        outs = (C.c_void_p * n_frames)(*[images[f, ((p + f) % n_parts) * block].data_ptr() for f in range(n_frames)])
+        st = _abi.rt_stats()
+        _abi.check(lib.rt_render_frames(world.device().handle, carr, n_frames, C.byref(r), w, h, 42, 54, 1, C.byref(part),
+                                        outs, torch.cuda.current_stream().cuda_stream, C.byref(st)))
+        total_rays += st.rays
+    torch.cuda.synchronize()
+    got = images.cpu().numpy()
+    for f in range(n_frames):
+        assert_bit_equal(got[f], refs[f], f"frame {f} assembled from rotating blocks")
+    # unequal parts are refused
+    bad = _abi.rt_partition(0, 4, 7, 1)
+    outs = (C.c_void_p * 1)(images[0].data_ptr())
+    assert lib.rt_render_frames(world.device().handle, carr, 1, C.byref(r), w, h, 42, 54, 1, C.byref(bad), outs, None, None) != 0
+    assert b"equal parts" in lib.rt_last_error()
