@@ -1,16 +1,21 @@
 #!/usr/bin/env python3
-"""bench.py — headline benchmark: path samples/s of examples/demo.yml, pathtracer, 1920x1080.
+"""bench.py — headline benchmark: path samples/s of examples/demo.yml, pathtracer, 1920x1080 (BASELINE config 3).
 
-A step = one ImageTracer::fire_all_rays pass (one whole frame) with the scene already resident in
-HBM and the image left in HBM.  Steps are issued as launches of B frames (rt_render_frames: the
-frames of a launch share one pixel queue on the GPU; default: the steps dealt evenly over the fewest launches
-of at most 128 frames) over F HIP streams (default 1; 2 with several GPUs, for the gather),
-so B*F frames are in flight; every frame is rendered in full, nothing is cached between frames.  N GPUs split EVERY
-frame by row tiles dealt round-robin (strong scaling), one process per GPU; every rank pushes its part of a
-launch into rank 0's buffers (mapped through HIP IPC handles) with a device-to-device copy that runs beside the next
-launch's render, a CPU-side barrier per launch tells rank 0 when the parts are complete, and rt_unpack_parts
-assembles the images there (--gather rccl, also the fallback when the handles cannot be exchanged: one RCCL gather
-per launch instead).
+A step = ImageTracer::fire_all_rays over whole frames with the World already resident in HBM and the images left in
+HBM: one frame per step on one GPU.  Steps are issued as launches of B frames (rt_render_frames: the frames of a
+launch share one pixel queue on the GPU); every frame is rendered in full, nothing is cached between frames.
+
+N GPUs (one process per GPU, torch.distributed):
+
+  weak (default for c3): a step is N frames, so every GPU keeps one frame's worth of work per step.  Every frame is
+      split into N contiguous row blocks; frame f's block (rank + f) % N is rendered by `rank` (rt_partition.rotate), so
+      over N frames every GPU renders every block once and the blocks' unequal costs balance.  A block lands in rank 0's
+      final image with one plain device-to-device copy over xGMI (rank 0 shares its images through a HIP IPC handle; the
+      copies run on a copy stream beside the next launch's render); rank 0 renders its own blocks in place.  No unpack
+      kernel, no per-launch barrier.  Fallback when the handle cannot be exchanged (--gather rccl): one RCCL gather per
+      launch, blocks placed by rank 0.
+  strong (default for c4 / c5, whose single frames are seconds of work): every frame is split by 1-row tiles dealt
+      round-robin, the parts are pushed into rank 0's buffers and rt_unpack_parts assembles them.
 
   python bench.py --gpus 1 --steps K --warmup W
   python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
@@ -20,24 +25,25 @@ import argparse
 import ctypes as C
 import json
 import os
+import statistics
 import sys
 import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-WIDTH, HEIGHT, AA = 1920, 1080, 1
 NUM_OF_RAYS, MAX_DEPTH, RR_LIMIT = 10, 3, 3
 INIT_STATE, INIT_SEQ = 42, 54
-EXPECTED_RAYS = 44180520            # oracle (strict math) ray count of this exact frame; tests/test_gpu_parity.py
+EXPECTED_RAYS_C3 = 44180520         # oracle (strict math) ray count of the headline frame; tests/test_gpu_parity.py
 PEAK_FP32_VECTOR_TFLOPS = 157.3     # MI355X_MICROARCH.md: spec, packed FMA counted as 2 flop
 PEAK_STRICT_NOFMA_TFLOPS = 78.6     # same issue rate with unfused mul/add (the reference forbids FMA contraction)
-# HBM bytes per frame of the default configuration, from profiles/r01c_rocprof_default.txt (rocprofv3
-# --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate passes, mean KB per dispatch over 4 dispatches that render
-# 1 + 24 + 2*120 = 265 frames: 191 and 1726500; FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for gfx950):
-# (2*191 + 1726500) KB * 4 / 265 = 26.1 MB.  The algorithmic minimum is the 24.9 MB image (12-byte pixel stores
-# fill cache lines partially; the scene is read once per block into LDS); the path is VALU-bound, not HBM-bound.
-TRAFFIC_BYTES_PER_FRAME = (2 * 191 + 1726500) * 1000 * 4 / 265
+# what tools/valu_bench.hip sustains on the box with unfused v_mul_f32 + v_add_f32 streams (profiles/r01_valu_microbench.txt)
+PEAK_MEASURED_NOFMA_TFLOPS = 61.6
+PEAK_MEASURED_NOFMA_SOURCE = "profiles/r01_valu_microbench.txt"
+# HBM bytes per c3 frame from rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes, gfx950 corrections of
+# MI355X_MICROARCH.md applied); see TRAFFIC_SOURCE.  Only reported for the configuration that was profiled.
+TRAFFIC_BYTES_PER_FRAME_C3 = (2 * 191 + 1726500) * 1000 * 4 / 265
+TRAFFIC_SOURCE = "profiles/r01c_rocprof_default.txt (1 GPU, c3, one-pass launches)"
 
 
 def partition_rows(height, part, n_parts, tile_rows):
@@ -49,59 +55,106 @@ def partition_rows(height, part, n_parts, tile_rows):
     return rows
 
 
+def rotating_block(rank, frame, n_parts):
+    """Weak scaling: the row block of `frame` that `rank` renders (rt_partition.rotate, include/rustracer_amd.h)."""
+    return (rank + frame) % n_parts
+
+
 def flops_per_ray(n_spheres, n_planes):
     """60 per sphere test, 40 per plane test, +62 hit tail, +46 shade."""
     return 60 * n_spheres + 40 * n_planes + 62 + 46
 
 
-def cpu_baseline(flat, cam, rr, threads):
-    """The CPU checker (oracle/, the reference's algorithm restated) on this box's host cores."""
+def host_threads():
+    """Threads for the CPU baseline: the harness's CPU share when it states one (OMP_NUM_THREADS on the GPU box),
+    else every core this process may run on."""
+    env = int(os.environ.get("OMP_NUM_THREADS", "0") or 0)
+    try:
+        avail = len(os.sched_getaffinity(0))
+    except AttributeError:
+        avail = os.cpu_count() or 1
+    return (env if env > 0 else avail), avail
+
+
+def workload(name, args):
+    """(world, camera factory, width, height, aa, label) of a BASELINE config."""
+    import rustracer_amd as ra  # noqa: F401
+    from rustracer_amd import scenes
+    if name == "c3":
+        w, h, aa = args.width or 1920, args.height or 1080, args.aa or 1
+        return scenes.demo_world(), scenes.demo_camera, w, h, aa, "examples/demo.yml scene (4 shapes)"
+    if name == "c4":
+        w, h, aa = args.width or 3840, args.height or 2160, args.aa or 1
+        return (scenes.flake_world(True), scenes.flake_camera, w, h, aa,
+                "examples/flake sphere-flake (228 shapes, checkered + image pigments)")
+    w, h, aa = args.width or 7680, args.height or 4320, args.aa or 4
+    return (scenes.random_spheres_world(10000), scenes.random_spheres_camera, w, h, aa,
+            "synthetic 10 000 random spheres + plane + sky (10 002 shapes)")
+
+
+def cpu_baseline(flat, cam, rr, w, h, aa, gpu_frame):
+    """The CPU checker (oracle/, the reference's algorithm restated: serial all_rays, one task per pixel, linear scan,
+    libm transcendentals) on this box's host cores, on the headline frame; also how far the GPU frame is from it."""
+    import numpy as np
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import oracle_lib as O
-    reps = 3
+    threads, avail = host_threads()
+    reps, img, st = 3, None, None
     t0 = time.perf_counter()
     for _ in range(reps):
-        _, st = O.fire_all_rays(flat, cam, rr, WIDTH, HEIGHT, INIT_STATE, INIT_SEQ, AA, math_mode=O.MATH_LIBM,
-                                n_threads=threads)
+        img, st = O.fire_all_rays(flat, cam, rr, w, h, INIT_STATE, INIT_SEQ, aa, math_mode=O.MATH_LIBM, n_threads=threads)
     dt = (time.perf_counter() - t0) / reps
-    return {"value": WIDTH * HEIGHT * AA * AA / dt, "unit": "path samples/s", "cores": threads, "kind": "port",
-            "sample": f"the full {WIDTH}x{HEIGHT} frame {reps} times ({st['rays']} rays each, {dt:.2f} s wall per frame "
-                      "incl. serial all_rays)",
-            "rays_per_s": st["rays"] / dt}
+    out = {"value": w * h * aa * aa / dt, "unit": "path samples/s", "cores": threads, "cores_visible": avail,
+           "kind": "port",
+           "sample": f"the full {w}x{h} frame {reps} times ({st['rays']} rays each, {dt:.2f} s wall per frame incl. serial "
+                     "all_rays); threads = the harness's CPU share (OMP_NUM_THREADS) when set, else all visible cores",
+           "rays_per_s": st["rays"] / dt}
+    outl = None
+    if gpu_frame is not None:
+        g, o = gpu_frame.astype(np.float64), img.astype(np.float64)
+        bad = (np.abs(g - o) > 1e-4 * np.maximum(np.abs(g), np.abs(o)) + 1e-9).any(axis=-1)
+        outl = {"outlier_pixels": int(bad.sum()), "pixels": int(bad.size), "fraction": float(bad.sum()) / bad.size,
+                "tolerance": "1e-4 relative per pixel", "against": "oracle with this box's libm (gnu-target reference semantics)"}
+    return out, outl
 
 
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=240)
-    ap.add_argument("--warmup", type=int, default=24)
-    ap.add_argument("--tile-rows", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=0, help="default: 240 (c3), 1 (c4, c5)")
+    ap.add_argument("--warmup", type=int, default=-1, help="default: 24 (c3), 0 (c4, c5)")
+    ap.add_argument("--config", choices=["c3", "c4", "c5"], default="c3",
+                    help="BASELINE.json config: c3 demo.yml 1920x1080 (the headline), c4 sphere-flake 3840x2160, "
+                         "c5 10k random spheres 7680x4320 16 spp")
+    ap.add_argument("--width", type=int, default=0)
+    ap.add_argument("--height", type=int, default=0)
+    ap.add_argument("--aa", type=int, default=0)
+    ap.add_argument("--scaling", choices=["auto", "weak", "strong"], default="auto",
+                    help="N > 1: weak = a step is N frames (rotating row blocks, c3's default); strong = every frame split N ways")
+    ap.add_argument("--repeats", type=int, default=0, help="timed regions of K steps each; the median is reported (default 5 for c3, 1 else)")
+    ap.add_argument("--tile-rows", type=int, default=1, help="strong scaling: rows per tile")
     ap.add_argument("--inflight", type=int, default=0,
                     help="launches in flight on separate HIP streams (1..4; default 1, with several GPUs 2)")
     ap.add_argument("--frames-per-launch", type=int, default=0,
                     help="frames rendered by one rt_render_frames launch (default: the steps dealt evenly over the "
-                         "fewest launches of at most 128 frames)")
-    ap.add_argument("--schedule", choices=["auto", "passes", "onepass"], default="auto",
-                    help="rt_scene_set_schedule: 'passes' = short passes (lowest single-frame latency), 'onepass' = one "
-                         "pass per launch (best throughput with many frames in flight); auto = onepass unless "
-                         "--frames-per-launch 1 on one stream")
+                         "fewest launches of at most 128 frames; several GPUs: at least 4 launches)")
+    ap.add_argument("--schedule", choices=["auto", "passes", "onepass"], default="auto")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-call-timing", action="store_true", help="skip the rt_fire_all_rays / single-frame latency legs")
     ap.add_argument("--dist-backend", choices=["nccl", "gloo"], default="nccl",
-                    help="gloo: rehearse the N > 1 path on a box with fewer GPUs than ranks (parts staged through host memory)")
+                    help="gloo: rehearse the N > 1 path on a box with fewer GPUs than ranks")
     ap.add_argument("--gather", choices=["rccl", "p2p"], default="p2p",
-                    help="N > 1: how the parts reach rank 0.  rccl: one gather collective per launch.  p2p: rank 0 shares "
-                         "its buffers through HIP IPC handles and every rank pushes its part with a device-to-device copy "
-                         "(copy engine: runs beside the next launch's render, which an RCCL kernel cannot), with a "
-                         "CPU-side barrier per launch; falls back to rccl if the handles cannot be exchanged")
+                    help="N > 1: how the parts reach rank 0.  p2p: rank 0 shares its buffers through HIP IPC handles and every "
+                         "rank pushes its part with device-to-device copies (copy engines: they run beside the next launch's "
+                         "render, which an RCCL kernel cannot); rccl: one gather collective per launch (also the fallback)")
     ap.add_argument("--verify", action="store_true",
-                    help="after the run, rank 0 compares every assembled image with a whole-frame render, bit for bit")
+                    help="after the run, rank 0 compares every assembled image it still holds with a whole-frame render, bit for bit")
     args = ap.parse_args()
 
     import torch
     import torch.distributed as dist
     import rustracer_amd as ra
     from rustracer_amd import _abi
-    from rustracer_amd.scenes import demo_camera, demo_world
     from rustracer_amd.world import flatten_camera
 
     world_size = int(os.environ.get("WORLD_SIZE", "1"))
@@ -113,255 +166,433 @@ def main():
     torch.cuda.set_device(device)
     lib = _abi.lib()
     _abi.check(lib.rt_init(device))
-    if world_size > 1:
+    N = world_size
+    if N > 1:
         if args.dist_backend == "nccl":
             dist.init_process_group("nccl", device_id=torch.device("cuda", device))
         else:
             dist.init_process_group("gloo")
 
-    scene = demo_world()
+    c3 = args.config == "c3"
+    steps = args.steps or (240 if c3 else 1)
+    warmup = args.warmup if args.warmup >= 0 else (24 if c3 else 0)
+    repeats = args.repeats or (5 if c3 else 1)
+    scene, camera_of, WIDTH, HEIGHT, AA, label = workload(args.config, args)
     flat = scene.flatten()
-    cam = flatten_camera(demo_camera(WIDTH, HEIGHT))
+    cam = flatten_camera(camera_of(WIDTH, HEIGHT))
     rr = ra.PathTracer(scene, ra.BLACK, NUM_OF_RAYS, MAX_DEPTH, RR_LIMIT).flatten()
     dev = scene.device()          # World resident in HBM before the timed region
-    # one stream: a launch of this size fills the GPU by itself, and launches that share it run slower than one
-    # after the other (measured: 240 steps 0.78 vs 0.79 ms/frame, 100 steps 0.79 vs 0.84); with several GPUs a
-    # second stream lets the gather of one launch run beside the next launch
-    F = max(1, min(args.inflight, 4)) if args.inflight else (2 if world_size > 1 else 1)
+    headline = c3 and (WIDTH, HEIGHT, AA) == (1920, 1080, 1)
+    weak = N > 1 and (args.scaling == "weak" or (args.scaling == "auto" and c3))
+    if weak and HEIGHT % N != 0:
+        raise SystemExit(f"weak scaling uses {N} equal row blocks: height {HEIGHT} is not divisible by {N}")
+    fpstep = N if weak else 1                       # frames per step
+    frame_bytes = WIDTH * HEIGHT * 12
+
+    # streams and launch sizes: one stream on one GPU (a launch of this size fills the GPU by itself, and launches that
+    # share it run slower than one after the other); several GPUs: two, so that one launch's drain of long pixels
+    # overlaps the next launch's bulk, and the copies of a launch run beside the next render
+    F = max(1, min(args.inflight, 4)) if args.inflight else (2 if N > 1 else 1)
+    total_frames = steps * fpstep
     if args.frames_per_launch:
         B = max(1, min(args.frames_per_launch, 512))
+    elif not c3:
+        B = 1                                        # c4 / c5: one frame is seconds of work
     else:
-        # the fewest launches of at most 128 frames, the steps dealt evenly over them: every launch ends with one
-        # drain of long pixels (measured, 240 steps: launches of 60 / 120 frames 0.78 / 0.75 ms/frame).  With
-        # several GPUs at least 4 launches, so that the gather of one can overlap the render of the next.
-        n_l = (args.steps + 127) // 128
-        if world_size > 1:
-            n_l = max(n_l, min(4, args.steps))
-        B = max(1, min((args.steps + n_l - 1) // n_l, 128))
+        n_l = (total_frames + 127) // 128
+        if N > 1:
+            n_l = max(n_l, min(4, steps))
+        B = max(1, min((total_frames + n_l - 1) // n_l, 128))
+    if weak:
+        B = max(N, (B + N - 1) // N * N)             # whole rotations: every launch is balanced over the ranks
     onepass = args.schedule == "onepass" or (args.schedule == "auto" and (F > 1 or B > 1))
     dev.set_schedule((0,) if onepass else ())
-
-    part = _abi.rt_partition(rank, world_size, args.tile_rows)
-    sizes = [lib.rt_partition_pixels(WIDTH, HEIGHT, C.byref(_abi.rt_partition(p, world_size, args.tile_rows)))
-             for p in range(world_size)]
-    stride = max(sizes)
-    # Launch l renders frames [l*B, l*B + n) on stream l % F with that slot's own buffers, so the long
-    # single-pixel dependency chains at the end of one launch overlap the bulk of the next ones (and,
-    # for N > 1, gather(l) overlaps render(l+1)).
     streams = [torch.cuda.Stream() for _ in range(F)]
     cams = (_abi.rt_camera * B)(*([cam] * B))
-    # p2p gather: two more sets of gathered / image buffers than launches in flight, so that a part pushed by launch l
-    # lands in a buffer whose previous reader (rank 0's unpack of launch l - NB) is known to have finished
-    cpu_group, remote = None, None
-    NB = F
-    bufs = gathered = None
-    if world_size > 1:
-        bufs = [torch.zeros((B, stride, 3), dtype=torch.float32, device="cuda") for _ in range(F)]
-        if args.gather == "p2p":
-            from torch.multiprocessing.reductions import reduce_tensor
-            NB = F + 2
-            cpu_group = dist.new_group(backend="gloo") if args.dist_backend == "nccl" else dist.group.WORLD
-            ok, box = 1, [None]
-            if rank == 0:
-                try:
-                    gathered = [torch.zeros((world_size, B, stride, 3), dtype=torch.float32, device="cuda") for _ in range(NB)]
-                    box[0] = [reduce_tensor(t) for t in gathered]
-                except Exception as e:   # noqa: BLE001 - any failure means: use the collective
-                    print(f"p2p gather unavailable on rank 0: {e}", file=sys.stderr)
-                    box[0], ok = None, 0
-            dist.broadcast_object_list(box, src=0, group=cpu_group)
-            if rank == 0:
-                remote = gathered
-            elif box[0] is None:
+
+    def launch_sizes(n_frames):
+        out, done = [], 0
+        while done < n_frames:
+            out.append(min(B, n_frames - done))
+            done += out[-1]
+        return out
+
+    def sync_all():
+        torch.cuda.synchronize()
+        if N > 1:
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    # --------------------------------------------------------------------------------------------------------------
+    # how the frames reach rank 0
+    # --------------------------------------------------------------------------------------------------------------
+    cpu_group = None
+    p2p = False
+    if N > 1:
+        cpu_group = dist.new_group(backend="gloo") if args.dist_backend == "nccl" else dist.group.WORLD
+
+    def share_from_rank0(make):
+        """rank 0 allocates tensors and shares them through HIP IPC handles; returns (local-or-mapped tensors, ok)."""
+        from torch.multiprocessing.reductions import reduce_tensor
+        ok, box, mine = 1, [None], None
+        if rank == 0:
+            try:
+                mine = make()
+                box[0] = [reduce_tensor(t) for t in mine]
+            except Exception as e:   # noqa: BLE001 - any failure means: use the collective
+                print(f"p2p gather unavailable on rank 0: {e}", file=sys.stderr)
+                box[0], ok = None, 0
+        dist.broadcast_object_list(box, src=0, group=cpu_group)
+        if rank != 0:
+            if box[0] is None:
                 ok = 0
             else:
                 try:
-                    remote = [fn(*a) for fn, a in box[0]]     # rank 0's buffers mapped into this process
-                    remote[0][rank, 0, :1].copy_(bufs[0][0, :1])  # a first write through the mapping, checked here
+                    mine = [fn(*a) for fn, a in box[0]]      # rank 0's buffers mapped into this process
+                    probe = torch.zeros(1, dtype=torch.float32, device="cuda")
+                    mine[0].view(-1)[:1].copy_(probe)        # a first write through the mapping, checked here
                     torch.cuda.synchronize()
                 except Exception as e:   # noqa: BLE001
                     print(f"p2p gather unavailable on rank {rank}: {e}", file=sys.stderr)
                     ok = 0
-            flag = torch.tensor([ok], dtype=torch.int32)
-            dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=cpu_group)
-            if int(flag[0]) == 0:
-                cpu_group, remote, gathered, NB = None, None, None, F
-        if remote is None and rank == 0:
-            gathered = [torch.zeros((world_size, B, stride, 3), dtype=torch.float32, device="cuda") for _ in range(F)]
-    images = [torch.zeros((B, HEIGHT, WIDTH, 3), dtype=torch.float32, device="cuda") for _ in range(NB)]
-    copy_done, unpack_done = {}, {}
+        flag = torch.tensor([ok], dtype=torch.int32)
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=cpu_group)
+        return mine, int(flag[0]) == 1
 
-    def out_ptrs(slot, n):
-        t = bufs[slot] if world_size > 1 else images[slot]
-        return (C.c_void_p * n)(*[t[b].data_ptr() for b in range(n)])
+    st_one = _abi.rt_stats()
+    whole = _abi.rt_partition(0, 1, 1, 0)
 
-    def launch(l, n, ev=None, stats=None):
-        slot = l % F
-        st = streams[slot]
-        with torch.cuda.stream(st):
-            if ev:
-                ev[0].record(st)
-            _abi.check(lib.rt_render_frames(dev.handle, cams, n, C.byref(rr), WIDTH, HEIGHT, INIT_STATE, INIT_SEQ, AA,
-                                            C.byref(part), out_ptrs(slot, n), st.cuda_stream, stats))
-            if ev:
-                ev[1].record(st)
-            if remote is not None:
-                # push this rank's part into rank 0's buffer (device-to-device copy on this stream); complete() does
-                # the rest once every rank's copy has landed
-                remote[l % NB][rank, :n].copy_(bufs[slot][:n], non_blocking=True)
-                copy_done[l] = torch.cuda.Event()
-                copy_done[l].record(st)
-            elif world_size > 1:
-                # the collective runs on RCCL's stream after st's render; work.wait() makes st (not the
-                # host) wait for it, so the slot's buffers are free again when st reaches its next launch
-                if args.dist_backend == "gloo":
-                    host = bufs[slot].cpu()
-                    hlist = [torch.empty_like(host) for _ in range(world_size)] if rank == 0 else None
-                    dist.gather(host, gather_list=hlist, dst=0)
-                    if rank == 0:
-                        gathered[slot].copy_(torch.stack(hlist))
-                elif rank == 0:
-                    glist = list(gathered[slot].unbind(0))
-                    dist.gather(bufs[slot], gather_list=glist, dst=0, async_op=True).wait()
-                else:
-                    dist.gather(bufs[slot], dst=0, async_op=True).wait()
-                if rank == 0:
-                    for b in range(n):
-                        _abi.check(lib.rt_unpack_parts(gathered[slot][0, b].data_ptr(), B * stride, world_size,
-                                                       args.tile_rows, WIDTH, HEIGHT, images[slot][b].data_ptr(),
-                                                       st.cuda_stream))
+    if weak:
+        # ---- weak scaling: rotating row blocks, in place ----
+        block_rows = HEIGHT // N
+        block_px = block_rows * WIDTH
+        ring = min(max(total_frames, warmup * fpstep, N), max(3 * B, int(16e9 // frame_bytes)))
+        ring = max(B, ring // B * B)                 # whole launches (B is a multiple of N): a launch never straddles the wrap
+        images = None
+        if args.gather == "p2p":
+            shared, p2p = share_from_rank0(lambda: [torch.zeros((ring, HEIGHT, WIDTH, 3), dtype=torch.float32, device="cuda")])
+            if p2p:
+                images = shared[0]
+        if images is None and rank == 0:
+            images = torch.zeros((ring, HEIGHT, WIDTH, 3), dtype=torch.float32, device="cuda")
+        NL = F + 1
+        direct = p2p and rank == 0                   # rank 0 renders its blocks in place
+        local = None if direct else [torch.zeros((B, block_px, 3), dtype=torch.float32, device="cuda") for _ in range(NL)]
+        gathered = None
+        if not p2p and rank == 0:
+            gathered = [torch.zeros((N, B, block_px, 3), dtype=torch.float32, device="cuda") for _ in range(F)]
+        cstream = torch.cuda.Stream()
+        copy_done = {}
 
-    def complete(l, n):
-        """p2p gather: launch l's parts are in rank 0's buffer l % NB once every rank's copy has finished (CPU barrier);
-        rank 0 then assembles the images.  Rank 0 enters the barrier of launch l only after its unpack of launch l - 2
-        has finished (its kernels run in the gaps the render leaves), which is what lets launch l + F overwrite that
-        buffer."""
-        copy_done.pop(l).synchronize()
-        if rank == 0 and (l - 2) in unpack_done:
-            unpack_done.pop(l - 2).synchronize()
-        dist.barrier(group=cpu_group)
-        if rank == 0:
+        def block_view(f):
+            """frame f's slot of the ring as (N blocks, block pixels, 3)"""
+            return images[f % ring].view(N, block_px, 3)
+
+        def launch(l, f0, n, ev=None, stats=None):
             st = streams[l % F]
-            for b in range(n):
-                _abi.check(lib.rt_unpack_parts(gathered[l % NB][0, b].data_ptr(), B * stride, world_size, args.tile_rows,
-                                               WIDTH, HEIGHT, images[l % NB][b].data_ptr(), st.cuda_stream))
-            unpack_done[l] = torch.cuda.Event()
-            unpack_done[l].record(st)
+            part = _abi.rt_partition(rotating_block(rank, f0, N), N, block_rows, 1)
+            with torch.cuda.stream(st):
+                if direct:
+                    ptrs = [block_view(f0 + b)[rotating_block(0, f0 + b, N)].data_ptr() for b in range(n)]
+                else:
+                    if (l - NL) in copy_done:            # the slot's previous copies have left it
+                        st.wait_event(copy_done.pop(l - NL))
+                    ptrs = [local[l % NL][b].data_ptr() for b in range(n)]
+                if ev:
+                    ev[0].record(st)
+                _abi.check(lib.rt_render_frames(dev.handle, cams, n, C.byref(rr), WIDTH, HEIGHT, INIT_STATE, INIT_SEQ, AA,
+                                                C.byref(part), (C.c_void_p * n)(*ptrs), st.cuda_stream, stats))
+                if ev:
+                    ev[1].record(st)
+                if direct:
+                    return
+                if p2p:
+                    rendered = torch.cuda.Event()
+                    rendered.record(st)
+                    with torch.cuda.stream(cstream):
+                        cstream.wait_event(rendered)
+                        for b in range(n):               # one plain copy per block, straight to its place in the final image
+                            block_view(f0 + b)[rotating_block(rank, f0 + b, N)].copy_(local[l % NL][b], non_blocking=True)
+                        copy_done[l] = torch.cuda.Event()
+                        copy_done[l].record(cstream)
+                else:
+                    buf = local[l % NL]
+                    if args.dist_backend == "gloo":
+                        host = buf.cpu()
+                        hlist = [torch.empty_like(host) for _ in range(N)] if rank == 0 else None
+                        dist.gather(host, gather_list=hlist, dst=0)
+                        if rank == 0:
+                            gathered[l % F].copy_(torch.stack(hlist))
+                    elif rank == 0:
+                        dist.gather(buf, gather_list=list(gathered[l % F].unbind(0)), dst=0, async_op=True).wait()
+                    else:
+                        dist.gather(buf, dst=0, async_op=True).wait()
+                    if rank == 0:
+                        for r in range(N):
+                            for b in range(n):
+                                block_view(f0 + b)[rotating_block(r, f0 + b, N)].copy_(gathered[l % F][r, b], non_blocking=True)
 
-    def run(steps, events=None):
-        sizes = []
-        done = 0
-        while done < steps:
-            sizes.append(min(B, steps - done))
-            done += sizes[-1]
-        for l, n in enumerate(sizes):
-            if remote is not None and l >= F:
-                complete(l - F, sizes[l - F])
-            launch(l, n, events[l] if events is not None else None)
-        if remote is not None:
-            for l in range(max(0, len(sizes) - F), len(sizes)):
-                complete(l, sizes[l])
-            unpack_done.clear()
-        return len(sizes)
+        def run(n_frames, events=None):
+            f0 = 0
+            sizes = launch_sizes(n_frames)
+            for l, n in enumerate(sizes):
+                if f0 > 0 and f0 % ring == 0:
+                    sync_all()                           # the ring wraps: everybody has finished with the old frames
+                launch(l, f0, n, events[l] if events is not None else None)
+                f0 += n
+            copy_done.clear()
+            return len(sizes)
 
-    def sync_all():
-        torch.cuda.synchronize()
-        if world_size > 1:
-            dist.barrier()
-            torch.cuda.synchronize()
-
-    # one instrumented single-frame launch: ray counters of this rank's part (deterministic, same every step)
-    st = _abi.rt_stats()
-    launch(0, 1, stats=C.byref(st))
-    if remote is not None:
-        complete(0, 1)
-        unpack_done.clear()
-    my_rays = st.rays
-    if world_size == 1 and my_rays != EXPECTED_RAYS and not os.environ.get("RUSTRACER_BENCH_ABLATION"):
-        raise SystemExit(f"ray counter {my_rays} != {EXPECTED_RAYS} (oracle, World::ray_intersection calls of this frame)")
-    sync_all()
-
-    run(args.warmup)
-    sync_all()
-    n_launches = (args.steps + B - 1) // B
-    events = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(n_launches)]
-    t0 = time.perf_counter()
-    run(args.steps, events)
-    sync_all()
-    dt = time.perf_counter() - t0
-
-    # per-launch latency (start -> end of the launch's kernels on its own stream; launches in flight
-    # stretch each other) and the device-side span of the whole timed region / launches = the effective
-    # duration of one launch
-    latency_ms = sum(a.elapsed_time(b) for a, b in events) / n_launches
-    span_ms = max(events[0][0].elapsed_time(e[1]) for e in events[-F:])
-    launch_ms = span_ms / n_launches
-    t = torch.tensor([dt, launch_ms, float(my_rays), latency_ms], dtype=torch.float64, device="cuda")
-    if world_size > 1:
-        tmax = t.clone()
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        tsum = t.clone()
-        dist.all_reduce(tsum, op=dist.ReduceOp.SUM)
-        dt, total_rays = float(tmax[0]), float(tsum[2])
+        # ray counters of this rank over one rotation (N frames: every block once)
+        launch(0, 0, N, stats=C.byref(st_one))
+        sync_all()
+        copy_done.clear()
+        my_rays_per_frame = st_one.rays / N          # this rank's share of a frame, averaged over the rotation
     else:
-        total_rays = float(my_rays)
+        # ---- one GPU, or strong scaling: every frame split by row tiles dealt round-robin, parts assembled on rank 0 ----
+        part = _abi.rt_partition(rank, N, args.tile_rows, 0)
+        sizes_px = [lib.rt_partition_pixels(WIDTH, HEIGHT, C.byref(_abi.rt_partition(p, N, args.tile_rows, 0))) for p in range(N)]
+        stride = max(sizes_px)
+        remote, NB = None, F
+        bufs = gathered = None
+        if N > 1:
+            bufs = [torch.zeros((B, stride, 3), dtype=torch.float32, device="cuda") for _ in range(F)]
+            if args.gather == "p2p":
+                # two more sets of gathered / image buffers than launches in flight, so that a part pushed by launch l lands
+                # in a buffer whose previous reader (rank 0's unpack of launch l - NB) is known to have finished
+                shared, p2p = share_from_rank0(lambda: [torch.zeros((N, B, stride, 3), dtype=torch.float32, device="cuda")
+                                                        for _ in range(F + 2)])
+                if p2p:
+                    remote, NB = shared, F + 2
+                    if rank == 0:
+                        gathered = shared
+            if remote is None and rank == 0:
+                gathered = [torch.zeros((N, B, stride, 3), dtype=torch.float32, device="cuda") for _ in range(F)]
+        images = [torch.zeros((B, HEIGHT, WIDTH, 3), dtype=torch.float32, device="cuda") for _ in range(NB)] if rank == 0 or N == 1 else None
+        copy_done, unpack_done = {}, {}
+
+        def out_ptrs(slot, n):
+            t = bufs[slot] if N > 1 else images[slot]
+            return (C.c_void_p * n)(*[t[b].data_ptr() for b in range(n)])
+
+        def launch(l, n, ev=None, stats=None):
+            slot = l % F
+            st = streams[slot]
+            with torch.cuda.stream(st):
+                if ev:
+                    ev[0].record(st)
+                _abi.check(lib.rt_render_frames(dev.handle, cams, n, C.byref(rr), WIDTH, HEIGHT, INIT_STATE, INIT_SEQ, AA,
+                                                C.byref(part), out_ptrs(slot, n), st.cuda_stream, stats))
+                if ev:
+                    ev[1].record(st)
+                if remote is not None:
+                    # push this rank's part into rank 0's buffer (device-to-device copy on this stream); complete() does
+                    # the rest once every rank's copy has landed
+                    remote[l % NB][rank, :n].copy_(bufs[slot][:n], non_blocking=True)
+                    copy_done[l] = torch.cuda.Event()
+                    copy_done[l].record(st)
+                elif N > 1:
+                    # the collective runs on RCCL's stream after st's render; work.wait() makes st (not the host) wait for
+                    # it, so the slot's buffers are free again when st reaches its next launch
+                    if args.dist_backend == "gloo":
+                        host = bufs[slot].cpu()
+                        hlist = [torch.empty_like(host) for _ in range(N)] if rank == 0 else None
+                        dist.gather(host, gather_list=hlist, dst=0)
+                        if rank == 0:
+                            gathered[slot].copy_(torch.stack(hlist))
+                    elif rank == 0:
+                        dist.gather(bufs[slot], gather_list=list(gathered[slot].unbind(0)), dst=0, async_op=True).wait()
+                    else:
+                        dist.gather(bufs[slot], dst=0, async_op=True).wait()
+                    if rank == 0:
+                        for b in range(n):
+                            _abi.check(lib.rt_unpack_parts(gathered[slot][0, b].data_ptr(), B * stride, N, args.tile_rows,
+                                                           WIDTH, HEIGHT, images[slot][b].data_ptr(), st.cuda_stream))
+
+        def complete(l, n):
+            """p2p gather: launch l's parts are in rank 0's buffer l % NB once every rank's copy has finished (CPU barrier);
+            rank 0 then assembles the images.  Rank 0 enters the barrier of launch l only after its unpack of launch l - 2
+            has finished, which is what lets launch l + F overwrite that buffer."""
+            copy_done.pop(l).synchronize()
+            if rank == 0 and (l - 2) in unpack_done:
+                unpack_done.pop(l - 2).synchronize()
+            dist.barrier(group=cpu_group)
+            if rank == 0:
+                st = streams[l % F]
+                for b in range(n):
+                    _abi.check(lib.rt_unpack_parts(gathered[l % NB][0, b].data_ptr(), B * stride, N, args.tile_rows,
+                                                   WIDTH, HEIGHT, images[l % NB][b].data_ptr(), st.cuda_stream))
+                unpack_done[l] = torch.cuda.Event()
+                unpack_done[l].record(st)
+
+        def run(n_frames, events=None):
+            sizes = launch_sizes(n_frames)
+            for l, n in enumerate(sizes):
+                if remote is not None and l >= F:
+                    complete(l - F, sizes[l - F])
+                launch(l, n, events[l] if events is not None else None)
+            if remote is not None:
+                for l in range(max(0, len(sizes) - F), len(sizes)):
+                    complete(l, sizes[l])
+                unpack_done.clear()
+            return len(sizes)
+
+        # one instrumented single-frame launch: ray counters of this rank's part (deterministic, same every step)
+        launch(0, 1, stats=C.byref(st_one))
+        if remote is not None:
+            complete(0, 1)
+            unpack_done.clear()
+        my_rays_per_frame = st_one.rays
+        if N == 1 and headline and st_one.rays != EXPECTED_RAYS_C3 and not os.environ.get("RUSTRACER_BENCH_ABLATION"):
+            raise SystemExit(f"ray counter {st_one.rays} != {EXPECTED_RAYS_C3} (oracle, World::ray_intersection calls of this frame)")
+        sync_all()
+
+    # --------------------------------------------------------------------------------------------------------------
+    # warm-up, then `repeats` timed regions of exactly `steps` steps each; the median region is reported
+    # --------------------------------------------------------------------------------------------------------------
+    if warmup:
+        run(warmup * fpstep)
+    sync_all()
+    n_launches = len(launch_sizes(total_frames))
+    regions = []
+    for _ in range(repeats):
+        events = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(n_launches)]
+        sync_all()
+        t0 = time.perf_counter()
+        run(total_frames, events)
+        sync_all()
+        dt = time.perf_counter() - t0
+        # per-launch latency (start -> end of the launch's kernels on its own stream; launches in flight stretch each
+        # other) and the device-side span of the whole region / launches = the effective duration of one launch
+        latency_ms = sum(a.elapsed_time(b) for a, b in events) / n_launches
+        span_ms = max(events[0][0].elapsed_time(e[1]) for e in events[-F:])
+        regions.append((dt, span_ms / n_launches, latency_ms))
+    t = torch.tensor([[r[0] for r in regions], [r[1] for r in regions], [r[2] for r in regions]], dtype=torch.float64, device="cuda")
+    rays_t = torch.tensor([float(my_rays_per_frame)], dtype=torch.float64, device="cuda")
+    if N > 1:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)      # every region: the slowest rank's clock
+        dist.all_reduce(rays_t, op=dist.ReduceOp.SUM)
+    region_s = [float(x) for x in t[0]]
+    order = sorted(range(repeats), key=lambda i: region_s[i])
+    mid = order[(repeats - 1) // 2]                   # the median region (lower median for even counts)
+    dt, launch_ms, latency_ms = region_s[mid], float(regions[mid][1]), float(regions[mid][2])
+    rays_per_frame = float(rays_t[0])                 # all ranks together
 
     if args.verify and rank == 0:
         ref = torch.zeros((HEIGHT, WIDTH, 3), dtype=torch.float32, device="cuda")
         _abi.check(lib.rt_render(dev.handle, C.byref(cam), C.byref(rr), WIDTH, HEIGHT, INIT_STATE, INIT_SEQ, AA, None,
                                  ref.data_ptr(), torch.cuda.current_stream().cuda_stream, None))
         torch.cuda.synchronize()
-        n_last = args.steps - (n_launches - 1) * B     # frames of the last launch
         checked = 0
-        for l in range(max(0, n_launches - NB), n_launches):   # the launches whose images are still in a buffer
-            n_chk = n_last if l == n_launches - 1 else B
-            for b in range(n_chk):
-                if not torch.equal(images[l % NB][b].view(torch.int32), ref.view(torch.int32)):
-                    raise SystemExit(f"verify: image {b} of launch {l} differs from the whole-frame render")
-            checked += n_chk
-        print(f"verify ok: {checked} images of the last {min(NB, n_launches)} launches bit-identical to a whole-frame render"
-              + (" (p2p gather)" if remote is not None else ""), file=sys.stderr)
+        if weak:
+            for f in range(min(ring, total_frames)):
+                if not torch.equal(images[f].view(torch.int32), ref.view(torch.int32)):
+                    raise SystemExit(f"verify: frame in ring slot {f} differs from the whole-frame render")
+                checked += 1
+            how = " (rotating blocks" + (", p2p copies in place)" if p2p else ", gather)")
+        else:
+            n_last = total_frames - (n_launches - 1) * B      # frames of the last launch
+            for l in range(max(0, n_launches - NB), n_launches):   # the launches whose images are still in a buffer
+                n_chk = n_last if l == n_launches - 1 else B
+                for b in range(n_chk):
+                    if not torch.equal(images[l % NB][b].view(torch.int32), ref.view(torch.int32)):
+                        raise SystemExit(f"verify: image {b} of launch {l} differs from the whole-frame render")
+                checked += n_chk
+            how = " (p2p gather)" if remote is not None else ""
+        print(f"verify ok: {checked} images bit-identical to a whole-frame render{how}", file=sys.stderr)
+
+    # --------------------------------------------------------------------------------------------------------------
+    # the drop-in call and the single resident frame (SURVEY §8(d): wall time of rt_fire_all_rays incl. H2D and D2H,
+    # median of >= 5 after 1 warm-up) -- one GPU, headline config
+    # --------------------------------------------------------------------------------------------------------------
+    call = None
+    gpu_frame = None
+    if N == 1 and c3 and not args.no_call_timing:
+        import numpy as np
+        host = np.zeros((HEIGHT, WIDTH, 3), dtype=np.float32)
+        wall, kern = [], []
+        for i in range(7):
+            st = _abi.rt_stats()
+            t0 = time.perf_counter()
+            _abi.check(lib.rt_fire_all_rays(*flat.args(), C.byref(cam), C.byref(rr), WIDTH, HEIGHT, INIT_STATE, INIT_SEQ, AA,
+                                            host.ctypes.data_as(C.POINTER(C.c_float)), C.byref(st)))
+            if i >= 2:                                # the first call uploads the World and allocates; one more to warm up
+                wall.append((time.perf_counter() - t0) * 1e3)
+                kern.append(st.kernel_ms)
+        gpu_frame = host
+        dev.set_schedule(())                          # the latency schedule (library default)
+        img1 = torch.zeros((HEIGHT, WIDTH, 3), dtype=torch.float32, device="cuda")
+        res = []
+        for i in range(6):
+            st = _abi.rt_stats()
+            _abi.check(lib.rt_render(dev.handle, C.byref(cam), C.byref(rr), WIDTH, HEIGHT, INIT_STATE, INIT_SEQ, AA, None,
+                                     img1.data_ptr(), torch.cuda.current_stream().cuda_stream, C.byref(st)))
+            if i >= 1:
+                res.append(st.kernel_ms)
+        dev.set_schedule((0,) if onepass else ())
+        call = {"call_ms": statistics.median(wall), "call_kernel_ms": statistics.median(kern),
+                "call_samples_per_s": WIDTH * HEIGHT * AA * AA / (statistics.median(wall) * 1e-3),
+                "frame_ms_resident": statistics.median(res),
+                "what": "call_ms: wall time of rt_fire_all_rays (host tables in, host image out: H2D, render, D2H), median of 5 "
+                        "after 2 warm-up calls; frame_ms_resident: kernel time of one rt_render, World and image in HBM, median of 5"}
 
     if rank == 0:
-        samples_per_step = WIDTH * HEIGHT * AA * AA
-        value = samples_per_step * args.steps / dt
-        fpr = flops_per_ray(dev_n_spheres(flat), dev_n_planes(flat))
-        # roofline of the dominant kernel (k_pass) on THIS rank: algorithmic flops of one launch / its
-        # effective duration (HIP events on the launch streams over the timed region)
-        frames_per_launch = args.steps / n_launches
-        achieved = my_rays * frames_per_launch * fpr / (launch_ms * 1e-3) / 1e12
+        samples_per_frame = WIDTH * HEIGHT * AA * AA
+        value = samples_per_frame * total_frames / dt
+        n_sph, n_pl = dev_n_spheres(flat), dev_n_planes(flat)
+        fpr = flops_per_ray(n_sph, n_pl)
+        # roofline of the dominant kernel (k_pass) on THIS rank: algorithmic flops of one launch / its effective duration
+        # (HIP events on the launch streams over the median timed region)
+        frames_per_launch = total_frames / n_launches
+        achieved = my_rays_per_frame * frames_per_launch * fpr / (launch_ms * 1e-3) / 1e12
+        profiled = N == 1 and headline and onepass
+        n_nodes, n_unb = C.c_uint32(), C.c_uint32()
+        lib.rt_scene_hierarchy_info(dev.handle, C.byref(n_nodes), C.byref(n_unb))
+        if N == 1:
+            par = "1 GPU, whole frames"
+        elif weak:
+            par = (f"weak: a step is {N} frames; every frame in {N} contiguous row blocks, frame f's block (rank + f) % {N} on "
+                   f"`rank`; " + ("blocks copied in place into rank 0's images over xGMI (HIP IPC + copy engines), no unpack"
+                                  if p2p else "RCCL gather per launch, blocks placed by rank 0"))
+        else:
+            par = (f"strong: row tiles ({args.tile_rows} rows) of every frame round-robin over {N} GPUs, "
+                   + ("peer-copy gather (HIP IPC)" if remote is not None else "RCCL gather") + " to rank 0, rt_unpack_parts")
         out = {
-            "metric": "path samples/sec (node) demo.yml pathtracer 1080p",
-            "value": value, "unit": "path samples/s", "n_gpus": world_size, "steps": args.steps,
-            "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True,
-            "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": f"examples/demo.yml scene (4 shapes), pathtracer n={NUM_OF_RAYS} d={MAX_DEPTH} "
-                                   f"rr={RR_LIMIT}, {WIDTH}x{HEIGHT}, aa={AA}, seeds {INIT_STATE}/{INIT_SEQ}",
-                       "parallelism": (f"row tiles ({args.tile_rows} rows) of every frame round-robin over {world_size} "
-                                       "GPU(s), " + ("peer-copy gather (HIP IPC)" if remote is not None else "RCCL gather") + " to rank 0")
-                                      if world_size > 1 else "1 GPU, whole frames",
-                       "frames_per_launch": B, "launches_in_flight": F,
-                       "schedule": "onepass" if onepass else "passes",
-                       "rays_per_frame": total_rays, "rays_per_s": total_rays * args.steps / dt},
+            "metric": "path samples/sec (node) demo.yml pathtracer 1080p" if c3 else f"path samples/sec (node) {args.config}",
+            "value": value, "unit": "path samples/s", "n_gpus": N, "steps": steps,
+            "warmup": warmup, "ms_per_step": dt / steps * 1e3, "higher_is_better": True,
+            "scaling": "weak" if (weak or N == 1) else "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"{label}, pathtracer n={NUM_OF_RAYS} d={MAX_DEPTH} rr={RR_LIMIT}, {WIDTH}x{HEIGHT}, aa={AA}, "
+                                   f"seeds {INIT_STATE}/{INIT_SEQ}",
+                       "baseline_config": args.config, "parallelism": par, "frames_per_step": fpstep,
+                       "frames_per_launch": B, "launches_in_flight": F, "schedule": "onepass" if onepass else "passes",
+                       "world_ray_intersection": ("exact-winner hierarchy (skipped tests not credited)" if n_nodes.value else "linear scan"),
+                       "rays_per_frame": rays_per_frame, "rays_per_s": rays_per_frame * total_frames / dt,
+                       "timed_regions": repeats, "region_ms": [x * 1e3 for x in region_s], "reported": "median region"},
             "roofline": {"bound": "valu", "achieved": achieved, "peak": PEAK_FP32_VECTOR_TFLOPS, "unit": "TFLOP/s",
                          "frac": achieved / PEAK_FP32_VECTOR_TFLOPS,
-                         "traffic": TRAFFIC_BYTES_PER_FRAME * frames_per_launch if TRAFFIC_BYTES_PER_FRAME else None,
+                         "traffic": TRAFFIC_BYTES_PER_FRAME_C3 * frames_per_launch if profiled else None,
+                         "traffic_source": TRAFFIC_SOURCE if profiled else None,
                          "kernel": "k_pass", "launch_ms": launch_ms, "launch_latency_ms": latency_ms,
-                         "rays_per_launch": my_rays * frames_per_launch, "flops_per_ray": fpr,
-                         "peak_strict_nofma": PEAK_STRICT_NOFMA_TFLOPS,
-                         "frac_strict_nofma": achieved / PEAK_STRICT_NOFMA_TFLOPS},
+                         "rays_per_launch": my_rays_per_frame * frames_per_launch, "flops_per_ray": fpr,
+                         "peak_strict_nofma": PEAK_STRICT_NOFMA_TFLOPS, "frac_strict_nofma": achieved / PEAK_STRICT_NOFMA_TFLOPS,
+                         "peak_measured_nofma": PEAK_MEASURED_NOFMA_TFLOPS, "peak_measured_nofma_source": PEAK_MEASURED_NOFMA_SOURCE,
+                         "frac_of_measured_nofma_ceiling": achieved / PEAK_MEASURED_NOFMA_TFLOPS,
+                         "note": "the reference's semantics forbid FMA contraction: 40 % of the 157.3 spec peak (62.9) is above "
+                                 "the measured ceiling of unfused mul+add streams (61.6)"},
         }
-        if world_size == 1 and not args.no_cpu_baseline:
-            threads = int(os.environ.get("OMP_NUM_THREADS", "0")) or min(os.cpu_count() or 1, 16)
-            out["cpu_baseline"] = cpu_baseline(flat, cam, rr, threads)
+        if call:
+            out["call"] = call
+        if N == 1 and not args.no_cpu_baseline and c3:
+            out["cpu_baseline"], outl = cpu_baseline(flat, cam, rr, WIDTH, HEIGHT, AA, gpu_frame)
+            if outl:
+                out["outlier_fraction_vs_libm"] = outl["fraction"]
+                out["libm_comparison"] = outl
         print(json.dumps(out), flush=True)
-    if world_size > 1:
-        if remote is not None:
-            # consumers let go of rank 0's buffers before rank 0 frees them
-            if rank != 0:
-                remote = None
-            torch.cuda.synchronize()
-            dist.barrier(group=cpu_group)
+    if N > 1:
+        images = None
+        torch.cuda.synchronize()
+        dist.barrier(group=cpu_group)       # consumers let go of rank 0's buffers before rank 0 frees them
         dist.destroy_process_group()
 
 
