@@ -241,6 +241,12 @@ int rt_renderer_solve(const rt_scene* scene, const rt_renderer* renderer, const 
 int rt_pcg_random(const uint64_t* init_state, const uint64_t* init_seq, uint64_t n_seeds,
                   uint32_t n_draws, uint32_t* out);
 
+/* Replaces BRDF::scatter_ray (src/material.rs:265-284; Diffuse :161-186 with create_onb_from_z, src/normal.rs:143-158;
+ * Specular :225-246) for a batch: rf = the two PCG floats per item (2n), incoming_dir / interaction_point / normal
+ * 3n floats each (the normal is used raw, as the reference hands it over), `depth` the new rays' depth. */
+int rt_brdf_scatter_ray(uint32_t brdf, const float* rf, const float* incoming_dir, const float* interaction_point,
+                        const float* normal, uint32_t depth, uint64_t n, rt_ray* out);
+
 /* Evaluate include/rt_strict_math.h on the GPU (fn: 0 sin, 1 cos, 2 atan2(y=a,x=b), 3 acos,
  * 4 a/b, 5 sqrt(a) as the render kernels compute it, 6 its short form for a == 0 or a >= 2^-96);
  * used to prove host/device bit-equality of the shared math. */

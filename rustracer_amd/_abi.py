@@ -106,6 +106,8 @@ SIGNATURES = {
     "rt_world_ray_intersection": (C.c_int, [C.c_void_p, P(rt_ray), C.c_uint64, P(rt_hit)]),
     "rt_renderer_solve": (C.c_int, [C.c_void_p, P(rt_renderer), P(rt_ray), P(rt_pcg), C.c_uint64,
                                     P(C.c_float)]),
+    "rt_brdf_scatter_ray": (C.c_int, [C.c_uint32, P(C.c_float), P(C.c_float), P(C.c_float), P(C.c_float), C.c_uint32,
+                                      C.c_uint64, P(rt_ray)]),
     "rt_pcg_random": (C.c_int, [P(C.c_uint64), P(C.c_uint64), C.c_uint64, C.c_uint32,
                                 P(C.c_uint32)]),
     "rt_strict_math_eval": (C.c_int, [C.c_int, P(C.c_float), P(C.c_float), C.c_uint64,

@@ -134,13 +134,19 @@ def _renderer(args, world, n):
     return DummyRenderer()
 
 
+def pfm_path_for(ldr_file):
+    """ldr_file.with_extension("").with_extension("pfm") (src/main.rs:225, :319): one extension is stripped, then
+    whatever extension is left is REPLACED: "a.b.png" -> "a.pfm"."""
+    return os.path.splitext(os.path.splitext(ldr_file)[0])[0] + ".pfm"
+
+
 def _trace_and_write(args, n, world, camera):
     """The common tail of demo and render (src/main.rs:223-248, :317-342)."""
     img = HdrImage(n["width"], n["height"])
     tracer = ImageTracer(img, camera)
     tracer.fire_all_rays(_renderer(args, world, n), n["init_state"], n["init_seq"], n["aa"])
     if args.output_pfm:
-        hdr_file = os.path.splitext(args.OUTPUT)[0] + ".pfm"
+        hdr_file = pfm_path_for(args.OUTPUT)
         img.write_pfm_file(hdr_file, "little")
         _info(args, f"{hdr_file!r} has been written to disk")
     img.normalize_image(n["factor"])

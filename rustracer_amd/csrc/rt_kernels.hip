@@ -1410,6 +1410,31 @@ __global__ __launch_bounds__(RT_BLOCK) void k_math(int fn, const float* __restri
     out[i] = r;
 }
 
+// BRDF::scatter_ray for a batch (src/material.rs:161-186, :225-246, :265-284): the render kernels' own
+// diffuse_scatter_dir / specular_scatter_dir, with the origin, tmin, tmax and depth the reference gives the new ray.
+__global__ __launch_bounds__(RT_BLOCK) void k_scatter(uint32_t brdf, const float* __restrict__ rf, const float* __restrict__ incoming,
+                                                      const float* __restrict__ point, const float* __restrict__ normal,
+                                                      uint32_t depth, uint64_t n, rt_ray* __restrict__ out) {
+    const uint64_t i = (uint64_t)blockIdx.x * RT_BLOCK + threadIdx.x;
+    if (i >= n) return;
+    const Vec3 nrm = {normal[3 * i], normal[3 * i + 1], normal[3 * i + 2]};
+    Vec3 d;
+    rt_ray r;
+    if (brdf == RT_BRDF_DIFFUSE) {
+        d = diffuse_scatter_dir(rf[2 * i], rf[2 * i + 1], nrm);
+        r.tmin = 1.0e-3f;                                   // material.rs:181
+    } else {
+        const Vec3 in = {incoming[3 * i], incoming[3 * i + 1], incoming[3 * i + 2]};
+        d = specular_scatter_dir(in, nrm);
+        r.tmin = 1e-5f;                                     // Ray::default (ray.rs:50)
+    }
+    r.origin[0] = point[3 * i]; r.origin[1] = point[3 * i + 1]; r.origin[2] = point[3 * i + 2];
+    r.dir[0] = d.x; r.dir[1] = d.y; r.dir[2] = d.z;
+    r.tmax = __builtin_inff();
+    r.depth = depth;
+    out[i] = r;
+}
+
 // Row-tile partition inverse: image pixel -> (part, local pixel) -> copy.
 __global__ __launch_bounds__(RT_BLOCK) void k_unpack(const float* __restrict__ parts, uint64_t part_stride_pixels, uint32_t n_parts,
                                                      uint32_t tile_rows, uint32_t width, uint32_t height, float* __restrict__ image) {

@@ -88,14 +88,17 @@ class HdrImage:
 
     # ---- tone mapping (src/hdrimage.rs:239-268) ----
     def average_luminosity(self):
-        """Sequential f32 sum of log10(DELTA + luminosity) in pixel order, then 10^(sum/N)."""
+        """Sequential f32 sum of f32::log10(DELTA + luminosity) in pixel order, then f32::powf(10, sum/N)
+        (src/hdrimage.rs:239-245).  Color::luminosity reduces with f32::max / f32::min, which ignore a NaN operand
+        (src/color.rs:33-36): fmax / fmin here."""
         px = self.pixels.reshape(-1, 3)
-        lum = ((px.max(axis=1) + px.min(axis=1)) * F(0.5)).astype(F)  # Color::luminosity (color.rs:33-36)
-        logs = np.log10((DELTA + lum).astype(np.float64)).astype(F)
-        total = F(0.0)
-        for v in logs:  # order-sensitive f32 accumulation (hdrimage.rs:240-243)
-            total = F(total + v)
-        return F(math.pow(10.0, float(F(total / F(len(logs))))))
+        lum = ((np.fmax.reduce(px, axis=1) + np.fmin.reduce(px, axis=1)) * F(0.5)).astype(F)
+        with np.errstate(all="ignore"):
+            logs = np.log10((DELTA + lum).astype(F))       # float32 in, float32 log10 out
+        # order-sensitive f32 accumulation (hdrimage.rs:240-243): cumsum of float32 adds left to right in float32
+        total = np.cumsum(logs, dtype=F)[-1] if len(logs) else F(0.0)
+        with np.errstate(all="ignore"):
+            return F(np.power(F(10.0), F(total / F(len(logs)))))
 
     def normalize_image(self, factor, luminosity=None):
         lum = self.average_luminosity() if luminosity is None else F(luminosity)
@@ -116,10 +119,11 @@ class HdrImage:
 
     def write_ldr_file(self, path, gamma=1.0):
         path = str(path)
-        if path.endswith(".png"):
+        ext = path.lower()                  # ImageFormat::from_path lower-cases the extension
+        if ext.endswith(".png"):
             from PIL import Image
             Image.fromarray(self.ldr_bytes(gamma, 8), "RGB").save(path, format="PNG")
-        elif path.endswith(".ff"):
+        elif ext.endswith(".ff"):
             rgb = self.ldr_bytes(gamma, 16)
             rgba = np.concatenate([rgb, np.full(rgb.shape[:2] + (1,), 65535, np.uint16)], axis=2)
             with open(path, "wb") as f:

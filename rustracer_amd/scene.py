@@ -4,7 +4,10 @@ Runs once per scene on the host and produces the Camera + World that are flatten
 C-ABI tables (include/rustracer_amd.h).  The grammar, the token stream, the error kinds and the
 source locations they carry follow the reference (src/scene.rs:387-1308) so that a file the
 reference accepts builds the same scene here and a file it rejects is rejected at the same
-line and column.  Written from the grammar, not transliterated.
+line and column.  The lexer (`InputStream`: one-character look-behind, location tracking, comment and
+whitespace skipping, the `match_*` / `parse_*` entry points) mirrors the reference's structure method for method,
+because reproducing its token locations and error kinds requires the same one-slot `unread` behaviour; it is host
+glue outside the GPU path.
 """
 import io
 import math

@@ -165,3 +165,30 @@ def test_rotating_row_blocks_land_in_place_without_unpack():
     outs = (C.c_void_p * 1)(images[0].data_ptr())
     assert lib.rt_render_frames(world.device().handle, carr, 1, C.byref(r), w, h, 42, 54, 1, C.byref(bad), outs, None, None) != 0
     assert b"equal parts" in lib.rt_last_error()
+
+
+def test_brdf_scatter_ray_units_against_the_oracle():
+    """SURVEY §8 a11 / a12 directly: Diffuse (cosine-weighted, ONB from the RAW normal) and Specular scatter_ray on the
+    GPU against oracle_scatter_ray, every f32 of the new ray; includes PCG floats of exactly 0 and 1, normals with
+    z = -1 (the ONB's singular direction) and non-unit normals."""
+    lib = _abi.lib()
+    rng = np.random.default_rng(11)
+    n = 4096
+    rf = (rng.integers(0, 2**32, (n, 2), dtype=np.uint64).astype(np.float32) * np.float32(2.0**-32)).astype(np.float32)
+    rf[0], rf[1], rf[2] = (0.0, 0.0), (1.0, 1.0), (0.0, 1.0)
+    normal = rng.normal(size=(n, 3)).astype(np.float32)
+    normal[: n // 2] /= np.linalg.norm(normal[: n // 2], axis=1, keepdims=True).astype(np.float32)   # half unit, half raw
+    normal[3], normal[4], normal[5] = (0, 0, -1), (0, 0, 1), (1e-8, 0, -1)
+    incoming = rng.normal(size=(n, 3)).astype(np.float32)
+    point = rng.uniform(-5, 5, size=(n, 3)).astype(np.float32)
+    for brdf in (_abi.RT_BRDF_DIFFUSE, _abi.RT_BRDF_SPECULAR):
+        got = (_abi.rt_ray * n)()
+        _abi.check(lib.rt_brdf_scatter_ray(brdf, O.fptr(rf), O.fptr(incoming), O.fptr(point), O.fptr(normal), 2, n, got))
+        for i in range(n):
+            ref = _abi.rt_ray()
+            O.lib().oracle_scatter_ray(brdf, float(rf[i, 0]), float(rf[i, 1]), O.fptr(incoming[i]), O.fptr(point[i]),
+                                       O.fptr(normal[i]), 2, O.MATH_STRICT, C.byref(ref))
+            a = np.array(list(got[i].origin) + list(got[i].dir) + [got[i].tmin, got[i].tmax], dtype=np.float32)
+            b = np.array(list(ref.origin) + list(ref.dir) + [ref.tmin, ref.tmax], dtype=np.float32)
+            assert_bit_equal(a, b, f"scatter_ray brdf={brdf} item {i}")
+            assert got[i].depth == ref.depth == 2

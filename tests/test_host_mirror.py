@@ -156,7 +156,8 @@ def test_write_pfm_image_and_file(tmp_path):
 def test_tone_mapping(tmp_path):
     img = ra.HdrImage(2, 1)
     img.set_pixel(0, 0, (5, 10, 15)); img.set_pixel(1, 0, (500, 1000, 1500))
-    assert abs(float(img.average_luminosity()) - 100.0) < 1e-3
+    # hdrimage.rs:779-791 at f32 exactness: log10f(10) = 1, log10f(1000) = 3, powf(10, 2) = 100
+    assert img.average_luminosity() == np.float32(100.0) and img.average_luminosity().dtype == np.float32
     img.normalize_image(1000.0, 100.0)
     assert np.allclose(img.get_pixel(0, 0), (0.5e2, 1e2, 1.5e2)) and np.allclose(img.get_pixel(1, 0), (0.5e4, 1e4, 1.5e4))
     img.clamp_image()
@@ -215,3 +216,27 @@ def test_partition_rows_bookkeeping():
         assert sorted(r for part in rows for r in part) == list(range(h))
         for p in range(n_parts):
             assert lib.rt_partition_pixels(13, h, C.byref(_abi.rt_partition(p, n_parts, tile))) == 13 * len(rows[p])
+
+
+def test_tone_mapping_f32_details():
+    """Color::luminosity ignores a NaN channel (f32::max / f32::min, src/color.rs:33-36); the extension match is
+    case-insensitive (ImageFormat::from_path); --output-pfm strips one extension and replaces the next (src/main.rs:225)."""
+    from rustracer_amd.cli import pfm_path_for
+    img = ra.HdrImage(2, 1)
+    img.set_pixel(0, 0, (5, float("nan"), 15)); img.set_pixel(1, 0, (500, 1000, 1500))
+    assert img.average_luminosity() == np.float32(100.0)          # max/min of (5, NaN, 15) = 15 / 5, as f32::max does
+    # sequential f32 accumulation, not pairwise: 2^24 + 1 + 1 ... stays 2^24 in f32
+    big = ra.HdrImage(5, 1)
+    lum = np.array([10.0 ** 7.5] + [10.0 ** 1e-7] * 4, dtype=np.float32)
+    big.set_pixels(np.repeat(lum[:, None], 3, axis=1).reshape(1, 5, 3))
+    logs = np.log10((np.float32(1e-10) + lum).astype(np.float32))
+    seq = np.float32(0.0)
+    for v in logs:
+        seq = np.float32(seq + v)
+    assert big.average_luminosity() == np.float32(np.power(np.float32(10.0), np.float32(seq / np.float32(5))))
+    assert pfm_path_for("x.y.png") == "x.pfm" and pfm_path_for("out.png") == "out.pfm" and pfm_path_for("d/a.ff") == "d/a.pfm"
+    img.normalize_image(1.0, 100.0); img.clamp_image()
+    import tempfile
+    with tempfile.TemporaryDirectory() as d:
+        img.write_ldr_file(os.path.join(d, "UPPER.PNG"))
+        assert os.path.getsize(os.path.join(d, "UPPER.PNG")) > 0
