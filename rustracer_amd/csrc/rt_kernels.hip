@@ -409,6 +409,7 @@ __global__ __launch_bounds__(RT_BLOCK, RT_WAVES_PER_EU) void k_pass(const PassPa
     uint64_t mstate = 0;            // master PCG state at the next jitter draw of q
     uint64_t pstate = 0, pinc = 1;  // the pixel's PCG (state before this round's draws)
     uint64_t pskip = 0;             // FAST: pinc * skip_plus (the increment part of skipping 2*num_of_rays draws)
+    uint32_t px_fr = 0, px_row = 0, px_col = 0;   // FAST: frame, image row and column of q (computed once per pixel)
     float acc_r = 0.f, acc_g = 0.f, acc_b = 0.f;
     bool busy = false;              // a top-level solve of q is in flight
     uint32_t lvl = 0;               // recursion level of the rays traced next (0 = the level-0 ray)
@@ -595,7 +596,8 @@ __global__ __launch_bounds__(RT_BLOCK, RT_WAVES_PER_EU) void k_pass(const PassPa
                     if (leader) {
                         if (K_MODE == 0u) {
                             uint32_t fr, lq, gr_, gc_;
-                            local_to_global(C, q, fr, lq, gr_, gc_);
+                            if (FAST) { fr = px_fr; lq = q - fr * C->n_per_frame; }
+                            else local_to_global(C, q, fr, lq, gr_, gc_);
                             float* o = frame_entry(C, fr)->out + 3ull * lq;
                             const float inv_samples = C->inv_samples;
                             o[0] = acc_r * inv_samples;
@@ -674,6 +676,7 @@ __global__ __launch_bounds__(RT_BLOCK, RT_WAVES_PER_EU) void k_pass(const PassPa
                     if (K_MODE == 0u) {
                         uint32_t fr, lq, grow, gcol;
                         local_to_global(C, q, fr, lq, grow, gcol);
+                        if (FAST) { px_fr = fr; px_row = grow; px_col = gcol; }
                         // master PCG at this pixel: jump ahead p*(2*aa^2+1) draws (imagetracer.rs:63-81),
                         // from the chunk's first pixel (a chunk that runs into the next frame restarts at 0)
                         const uint32_t gp = grow * C->width + gcol;
@@ -764,9 +767,7 @@ __global__ __launch_bounds__(RT_BLOCK, RT_WAVES_PER_EU) void k_pass(const PassPa
                 if (lvl == 0u) {
                     // the level-0 ray of sample samp-1 (imagetracer.rs:52-56, :67-75)
                     ColdParams C = cold_params();
-                    uint32_t fr, lq, grow, gcol;
-                    local_to_global(C, q, fr, lq, grow, gcol);
-                    primary_ray<AFFINE>(C, frame_entry(C, fr), grow, gcol, samp - 1u, mstate, o, d);
+                    primary_ray<AFFINE>(C, frame_entry(C, px_fr), px_row, px_col, samp - 1u, mstate, o, d);
                     tmin = 1e-5f;                                   // Ray::default (ray.rs:50)
                 } else {
                     // BRDF::scatter_ray of the next child of the open hit (render.rs:160-166)
