@@ -143,10 +143,13 @@ def main():
     ap.add_argument("--no-call-timing", action="store_true", help="skip the rt_fire_all_rays / single-frame latency legs")
     ap.add_argument("--dist-backend", choices=["nccl", "gloo"], default="nccl",
                     help="gloo: rehearse the N > 1 path on a box with fewer GPUs than ranks")
-    ap.add_argument("--gather", choices=["rccl", "p2p"], default="p2p",
-                    help="N > 1: how the parts reach rank 0.  p2p: rank 0 shares its buffers through HIP IPC handles and every "
-                         "rank pushes its part with device-to-device copies (copy engines: they run beside the next launch's "
-                         "render, which an RCCL kernel cannot); rccl: one gather collective per launch (also the fallback)")
+    ap.add_argument("--gather", choices=["direct", "p2p", "rccl"], default="direct",
+                    help="N > 1: how the pixels reach rank 0.  direct: rank 0 shares its final images through a HIP IPC handle and "
+                         "every rank's render kernel stores its pixels in place, across xGMI, beside the render (no copy, no "
+                         "unpack, one launch; measured over PCIe on one GPU: 28.6 GB/s of pixel stores at no cost to the kernel, "
+                         "profiles/r02_remote_store_probe.jsonl).  p2p: parts rendered locally, pushed with device-to-device "
+                         "copies (copy engines, beside the next launch's render).  rccl: one gather collective per launch.  Each "
+                         "falls back to the next when the handle cannot be exchanged")
     ap.add_argument("--verify", action="store_true",
                     help="after the run, rank 0 compares every assembled image it still holds with a whole-frame render, bit for bit")
     args = ap.parse_args()
@@ -192,7 +195,7 @@ def main():
     # streams and launch sizes: one stream on one GPU (a launch of this size fills the GPU by itself, and launches that
     # share it run slower than one after the other); several GPUs: two, so that one launch's drain of long pixels
     # overlaps the next launch's bulk, and the copies of a launch run beside the next render
-    F = max(1, min(args.inflight, 4)) if args.inflight else (2 if N > 1 else 1)
+    F = max(1, min(args.inflight, 4)) if args.inflight else (2 if (N > 1 and args.gather != "direct") else 1)
     total_frames = steps * fpstep
     if args.frames_per_launch:
         B = max(1, min(args.frames_per_launch, 512))
@@ -200,8 +203,8 @@ def main():
         B = 1                                        # c4 / c5: one frame is seconds of work
     else:
         n_l = (total_frames + 127) // 128
-        if N > 1:
-            n_l = max(n_l, min(4, steps))
+        if N > 1 and args.gather != "direct":
+            n_l = max(n_l, min(4, steps))            # copies of one launch run beside the next launch's render
         B = max(1, min((total_frames + n_l - 1) // n_l, 128))
     if weak:
         B = max(N, (B + N - 1) // N * N)             # whole rotations: every launch is balanced over the ranks
@@ -260,9 +263,54 @@ def main():
         return mine, int(flag[0]) == 1
 
     st_one = _abi.rt_stats()
-    whole = _abi.rt_partition(0, 1, 1, 0)
+    direct = False
+    ring = 0
+    images = None
+    if N > 1 and args.gather == "direct":
+        # ---- every rank's kernel stores its pixels in place in rank 0's final images (rt_partition.in_place) ----
+        ring = min(max(total_frames, warmup * fpstep, N), max(3 * B, int(16e9 // frame_bytes)))
+        ring = max(B, ring // B * B)                 # whole launches: a launch never straddles the wrap
+        shared, direct = share_from_rank0(lambda: [torch.zeros((ring, HEIGHT, WIDTH, 3), dtype=torch.float32, device="cuda")])
+        if direct:
+            images = shared[0]
+        else:
+            args.gather = "p2p"
+            F = max(1, min(args.inflight, 4)) if args.inflight else 2
+            streams = [torch.cuda.Stream() for _ in range(F)]
 
-    if weak:
+    if direct:
+        block_rows = HEIGHT // N if weak else args.tile_rows
+
+        def launch(l, f0, n, ev=None, stats=None):
+            st = streams[l % F]
+            if weak:
+                part = _abi.rt_partition(rotating_block(rank, f0, N), N, block_rows, 1, 1)
+            else:
+                part = _abi.rt_partition(rank, N, block_rows, 0, 1)
+            with torch.cuda.stream(st):
+                ptrs = [images[(f0 + b) % ring].data_ptr() for b in range(n)]      # the FULL images; pixels land at their place
+                if ev:
+                    ev[0].record(st)
+                _abi.check(lib.rt_render_frames(dev.handle, cams, n, C.byref(rr), WIDTH, HEIGHT, INIT_STATE, INIT_SEQ, AA,
+                                                C.byref(part), (C.c_void_p * n)(*ptrs), st.cuda_stream, stats))
+                if ev:
+                    ev[1].record(st)
+
+        def run(n_frames, events=None):
+            f0 = 0
+            sizes = launch_sizes(n_frames)
+            for l, n in enumerate(sizes):
+                if f0 > 0 and f0 % ring == 0:
+                    sync_all()                           # the ring wraps: everybody has finished with the old frames
+                launch(l, f0, n, events[l] if events is not None else None)
+                f0 += n
+            return len(sizes)
+
+        n_probe = N if weak else 1                       # weak: one rotation (every block once)
+        launch(0, 0, n_probe, stats=C.byref(st_one))
+        sync_all()
+        my_rays_per_frame = st_one.rays / n_probe
+    elif weak:
         # ---- weak scaling: rotating row blocks, in place ----
         block_rows = HEIGHT // N
         block_px = block_rows * WIDTH
@@ -276,8 +324,8 @@ def main():
         if images is None and rank == 0:
             images = torch.zeros((ring, HEIGHT, WIDTH, 3), dtype=torch.float32, device="cuda")
         NL = F + 1
-        direct = p2p and rank == 0                   # rank 0 renders its blocks in place
-        local = None if direct else [torch.zeros((B, block_px, 3), dtype=torch.float32, device="cuda") for _ in range(NL)]
+        own_in_place = p2p and rank == 0             # rank 0 renders its blocks in place
+        local = None if own_in_place else [torch.zeros((B, block_px, 3), dtype=torch.float32, device="cuda") for _ in range(NL)]
         gathered = None
         if not p2p and rank == 0:
             gathered = [torch.zeros((N, B, block_px, 3), dtype=torch.float32, device="cuda") for _ in range(F)]
@@ -290,9 +338,9 @@ def main():
 
         def launch(l, f0, n, ev=None, stats=None):
             st = streams[l % F]
-            part = _abi.rt_partition(rotating_block(rank, f0, N), N, block_rows, 1)
+            part = _abi.rt_partition(rotating_block(rank, f0, N), N, block_rows, 1, 0)
             with torch.cuda.stream(st):
-                if direct:
+                if own_in_place:
                     ptrs = [block_view(f0 + b)[rotating_block(0, f0 + b, N)].data_ptr() for b in range(n)]
                 else:
                     if (l - NL) in copy_done:            # the slot's previous copies have left it
@@ -304,7 +352,7 @@ def main():
                                                 C.byref(part), (C.c_void_p * n)(*ptrs), st.cuda_stream, stats))
                 if ev:
                     ev[1].record(st)
-                if direct:
+                if own_in_place:
                     return
                 if p2p:
                     rendered = torch.cuda.Event()
@@ -350,8 +398,8 @@ def main():
         my_rays_per_frame = st_one.rays / N          # this rank's share of a frame, averaged over the rotation
     else:
         # ---- one GPU, or strong scaling: every frame split by row tiles dealt round-robin, parts assembled on rank 0 ----
-        part = _abi.rt_partition(rank, N, args.tile_rows, 0)
-        sizes_px = [lib.rt_partition_pixels(WIDTH, HEIGHT, C.byref(_abi.rt_partition(p, N, args.tile_rows, 0))) for p in range(N)]
+        part = _abi.rt_partition(rank, N, args.tile_rows, 0, 0)
+        sizes_px = [lib.rt_partition_pixels(WIDTH, HEIGHT, C.byref(_abi.rt_partition(p, N, args.tile_rows, 0, 0))) for p in range(N)]
         stride = max(sizes_px)
         remote, NB = None, F
         bufs = gathered = None
@@ -484,12 +532,13 @@ def main():
                                  ref.data_ptr(), torch.cuda.current_stream().cuda_stream, None))
         torch.cuda.synchronize()
         checked = 0
-        if weak:
+        if weak or direct:
             for f in range(min(ring, total_frames)):
                 if not torch.equal(images[f].view(torch.int32), ref.view(torch.int32)):
                     raise SystemExit(f"verify: frame in ring slot {f} differs from the whole-frame render")
                 checked += 1
-            how = " (rotating blocks" + (", p2p copies in place)" if p2p else ", gather)")
+            how = (" (pixels stored in place by every rank's kernel)" if direct else
+                   " (rotating blocks" + (", p2p copies in place)" if p2p else ", gather)"))
         else:
             n_last = total_frames - (n_launches - 1) * B      # frames of the last launch
             for l in range(max(0, n_launches - NB), n_launches):   # the launches whose images are still in a buffer
@@ -550,13 +599,18 @@ def main():
         lib.rt_scene_hierarchy_info(dev.handle, C.byref(n_nodes), C.byref(n_unb))
         if N == 1:
             par = "1 GPU, whole frames"
+        elif direct:
+            par = ((f"weak: a step is {N} frames; every frame in {N} contiguous row blocks, frame f's block (rank + f) % {N} on `rank`"
+                    if weak else f"strong: row tiles ({args.tile_rows} rows) of every frame round-robin over {N} GPUs")
+                   + "; every rank's kernel stores its pixels in place in rank 0's final images over xGMI (HIP IPC mapping): "
+                     "no copy, no unpack, no per-launch barrier")
         elif weak:
             par = (f"weak: a step is {N} frames; every frame in {N} contiguous row blocks, frame f's block (rank + f) % {N} on "
                    f"`rank`; " + ("blocks copied in place into rank 0's images over xGMI (HIP IPC + copy engines), no unpack"
                                   if p2p else "RCCL gather per launch, blocks placed by rank 0"))
         else:
             par = (f"strong: row tiles ({args.tile_rows} rows) of every frame round-robin over {N} GPUs, "
-                   + ("peer-copy gather (HIP IPC)" if remote is not None else "RCCL gather") + " to rank 0, rt_unpack_parts")
+                   + ("peer-copy gather (HIP IPC)" if (N > 1 and remote is not None) else "RCCL gather") + " to rank 0, rt_unpack_parts")
         out = {
             "metric": "path samples/sec (node) demo.yml pathtracer 1080p" if c3 else f"path samples/sec (node) {args.config}",
             "value": value, "unit": "path samples/s", "n_gpus": N, "steps": steps,

@@ -113,10 +113,15 @@ typedef struct rt_pcg {
  * rotate != 0 (multi-frame launches): frame f of the launch renders part (part + f) % n_parts instead, so over
  * n_parts consecutive frames every GPU renders every part once.  With tile_rows = height / n_parts a part is one
  * contiguous block of rows that lands in the final image with a plain copy (no rt_unpack_parts) and the rotation
- * balances the blocks' unequal costs over the frames.  Needs equal parts: height % (tile_rows * n_parts) == 0. */
+ * balances the blocks' unequal costs over the frames.  Needs equal parts: height % (tile_rows * n_parts) == 0.
+ * in_place != 0: d_out_rgb is the FULL image (width * height * 3 floats) and every pixel of the part is stored at its
+ * global (row, column) -- the buffer may be another GPU's memory (an IPC mapping: the stores cross xGMI beside the
+ * render) or pinned host memory, so the parts of all GPUs assemble in one image with no copy and no rt_unpack_parts.
+ * in_place == 0: d_out_rgb holds only the part, rows in part-local order. */
 typedef struct rt_partition {
     uint32_t part, n_parts, tile_rows;
     uint32_t rotate;
+    uint32_t in_place;
 } rt_partition;
 
 /* Counters of one render call. */

@@ -63,7 +63,8 @@ class rt_pcg(C.Structure):
 
 
 class rt_partition(C.Structure):
-    _fields_ = [("part", C.c_uint32), ("n_parts", C.c_uint32), ("tile_rows", C.c_uint32), ("rotate", C.c_uint32)]
+    _fields_ = [("part", C.c_uint32), ("n_parts", C.c_uint32), ("tile_rows", C.c_uint32), ("rotate", C.c_uint32),
+                ("in_place", C.c_uint32)]
 
 
 class rt_stats(C.Structure):

@@ -96,6 +96,7 @@ struct PassParams {
     uint32_t part, n_parts, tile_rows;
     uint32_t part_rotate;
     uint32_t mg_parts[3];            // magic division by n_parts
+    uint32_t out_in_place;           // FrameEntry.out is the FULL image: a pixel is stored at its global (row, column)
     // exact u32 division by invariant divisors (Granlund-Montgomery, host: magic_u32): width, n_per_frame, tile_rows
     uint32_t mg_width[3], mg_npf[3], mg_tile[3];
     uint32_t n_items;                // n_frames * (pixels of this part) / solve items
@@ -596,8 +597,9 @@ __global__ __launch_bounds__(RT_BLOCK, RT_WAVES_PER_EU) void k_pass(const PassPa
                     if (leader) {
                         if (K_MODE == 0u) {
                             uint32_t fr, lq, gr_, gc_;
-                            if (FAST) { fr = px_fr; lq = q - fr * C->n_per_frame; }
+                            if (FAST) { fr = px_fr; lq = q - fr * C->n_per_frame; gr_ = px_row; gc_ = px_col; }
                             else local_to_global(C, q, fr, lq, gr_, gc_);
+                            if (C->out_in_place != 0u) lq = gr_ * C->width + gc_;
                             float* o = frame_entry(C, fr)->out + 3ull * lq;
                             const float inv_samples = C->inv_samples;
                             o[0] = acc_r * inv_samples;
@@ -1335,7 +1337,7 @@ __global__ __launch_bounds__(RT_BLOCK) void k_simple(const PassParams P, const D
         acc_r = acc_r + vr; acc_g = acc_g + vg; acc_b = acc_b + vb;     // imagetracer.rs:119
     }
     if (i_raw < n_items) {
-        float* out = F->out + 3ull * lq;
+        float* out = F->out + 3ull * (C->out_in_place != 0u ? grow * C->width + gcol : lq);
         const float inv_samples = C->inv_samples;                       // imagetracer.rs:121
         out[0] = acc_r * inv_samples;
         out[1] = acc_g * inv_samples;

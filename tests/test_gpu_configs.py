@@ -192,3 +192,51 @@ def test_brdf_scatter_ray_units_against_the_oracle():
             b = np.array(list(ref.origin) + list(ref.dir) + [ref.tmin, ref.tmax], dtype=np.float32)
             assert_bit_equal(a, b, f"scatter_ray brdf={brdf} item {i}")
             assert got[i].depth == ref.depth == 2
+
+
+def test_in_place_parts_assemble_in_one_image():
+    """rt_partition.in_place: every part stores its pixels at their global position in ONE full-size image (what each
+    GPU's kernel does to rank 0's image across xGMI): 1-row tiles, 3-row tiles, and rotating blocks over several frames."""
+    import torch
+    lib = _abi.lib()
+    w, h = 120, 64
+    world = demo_world()
+    rr = ra.PathTracer(world, ra.BLACK, 10, 3, 3)
+    r = rr.flatten()
+    cam = demo_camera(w, h)
+    ref, rs = oracle(world, cam, rr, w, h)
+    c = flatten_camera(cam)
+    for n_parts, tile_rows in ((4, 1), (3, 3), (8, 8)):
+        image = torch.full((h, w, 3), float("nan"), dtype=torch.float32, device="cuda")
+        rays = 0
+        for p in range(n_parts):
+            part = _abi.rt_partition(p, n_parts, tile_rows, 0, 1)
+            st = _abi.rt_stats()
+            _abi.check(lib.rt_render(world.device().handle, C.byref(c), C.byref(r), w, h, 42, 54, 1, C.byref(part),
+                                     image.data_ptr(), torch.cuda.current_stream().cuda_stream, C.byref(st)))
+            rays += st.rays
+        assert_bit_equal(image.cpu().numpy(), ref, f"in place {n_parts} parts x {tile_rows} rows")
+        assert rays == rs["rays"]
+    # flat renderer (the image kernel), antialiased, in place
+    fl = ra.FlatRenderer(world, ra.BLACK)
+    ref2, _ = oracle(world, cam, fl, w, h, aa=2)
+    image = torch.full((h, w, 3), float("nan"), dtype=torch.float32, device="cuda")
+    f = fl.flatten()
+    for p in range(2):
+        part = _abi.rt_partition(p, 2, 1, 0, 1)
+        _abi.check(lib.rt_render(world.device().handle, C.byref(c), C.byref(f), w, h, 42, 54, 2, C.byref(part),
+                                 image.data_ptr(), torch.cuda.current_stream().cuda_stream, None))
+    torch.cuda.synchronize()
+    assert_bit_equal(image.cpu().numpy(), ref2, "flat, in place")
+    # rotating blocks of 4 frames, in place
+    n_parts, n_frames = 4, 4
+    images = torch.full((n_frames, h, w, 3), float("nan"), dtype=torch.float32, device="cuda")
+    carr = (_abi.rt_camera * n_frames)(*([c] * n_frames))
+    outs = (C.c_void_p * n_frames)(*[images[k].data_ptr() for k in range(n_frames)])
+    for p in range(n_parts):
+        part = _abi.rt_partition(p, n_parts, h // n_parts, 1, 1)
+        _abi.check(lib.rt_render_frames(world.device().handle, carr, n_frames, C.byref(r), w, h, 42, 54, 1, C.byref(part), outs,
+                                        torch.cuda.current_stream().cuda_stream, None))
+    torch.cuda.synchronize()
+    for k in range(n_frames):
+        assert_bit_equal(images[k].cpu().numpy(), ref, f"rotating blocks in place, frame {k}")

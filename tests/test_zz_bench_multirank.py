@@ -1,8 +1,9 @@
 """bench.py's N-rank paths rehearsed on one GPU: 2 ranks share the card (gloo for the control plane).
 
 weak (the c3 default): a step is 2 frames, every frame in 2 contiguous row blocks, frame f's block (rank + f) % 2 on
-`rank`, blocks copied in place into rank 0's images through a HIP IPC mapping (p2p) or gathered by a collective and
-placed by rank 0.  strong: every frame split by 1-row tiles, parts pushed / gathered and assembled by rt_unpack_parts.
+`rank`.  strong: every frame split by 1-row tiles.  The pixels reach rank 0's images either stored in place by every
+rank's render kernel through a HIP IPC mapping (direct, the default), or as parts copied device-to-device (p2p), or
+gathered by a collective (placed by rank 0 / assembled by rt_unpack_parts).
 In every case rank 0's images must be bit-identical to a whole-frame render (--verify).  The collective variant runs
 over gloo with host staging here (two ranks cannot share one GPU under RCCL): it exercises bench.py's control flow,
 not RCCL.  Collected late on purpose: it starts child processes."""
@@ -24,16 +25,18 @@ def _free_port():
         return s.getsockname()[1]
 
 
-@pytest.mark.parametrize("scaling,gather", [("weak", "p2p"), ("weak", "staged-collective"), ("strong", "p2p"),
-                                            ("strong", "staged-collective")])
+@pytest.mark.parametrize("scaling,gather", [("weak", "direct"), ("strong", "direct"), ("weak", "p2p"), ("weak", "staged-collective"),
+                                            ("strong", "p2p"), ("strong", "staged-collective")])
 def test_two_ranks_on_one_gpu_assemble_bit_identical_frames(scaling, gather):
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
            "--master-port", str(_free_port()), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "6", "--warmup", "2",
            "--repeats", "2", "--dist-backend", "gloo", "--scaling", scaling,
-           "--gather", "p2p" if gather == "p2p" else "rccl", "--verify"]
+           "--gather", gather if gather in ("p2p", "direct") else "rccl", "--verify"]
     r = subprocess.run(cmd, cwd=ROOT, capture_output=True, text=True, timeout=280)
     assert r.returncode == 0, r.stderr[-2000:]
     assert "verify ok" in r.stderr, r.stderr[-2000:]
-    if gather == "p2p":       # the handles were exchanged: no silent fallback here
+    if gather == "direct":    # the handle was exchanged: no silent fallback here
+        assert "pixels stored in place by every rank's kernel" in r.stderr, r.stderr[-2000:]
+    if gather == "p2p":
         assert ("p2p copies in place" if scaling == "weak" else "(p2p gather)") in r.stderr, r.stderr[-2000:]
     assert '"n_gpus": 2' in r.stdout and f'"scaling": "{scaling}"' in r.stdout
