@@ -198,14 +198,16 @@ def main():
     F = max(1, min(args.inflight, 4)) if args.inflight else (2 if (N > 1 and args.gather != "direct") else 1)
     total_frames = steps * fpstep
     if args.frames_per_launch:
-        B = max(1, min(args.frames_per_launch, 512))
+        B = max(1, min(args.frames_per_launch, 1024))
     elif not c3:
         B = 1                                        # c4 / c5: one frame is seconds of work
     else:
-        n_l = (total_frames + 127) // 128
+        # the fewest launches of at most 128 frames' worth of work per GPU (every launch ends with one drain of long pixels)
+        cap = 128 * fpstep
+        n_l = (total_frames + cap - 1) // cap
         if N > 1 and args.gather != "direct":
             n_l = max(n_l, min(4, steps))            # copies of one launch run beside the next launch's render
-        B = max(1, min((total_frames + n_l - 1) // n_l, 128))
+        B = max(1, min((total_frames + n_l - 1) // n_l, cap))
     if weak:
         B = max(N, (B + N - 1) // N * N)             # whole rotations: every launch is balanced over the ranks
     onepass = args.schedule == "onepass" or (args.schedule == "auto" and (F > 1 or B > 1))
@@ -268,7 +270,7 @@ def main():
     images = None
     if N > 1 and args.gather == "direct":
         # ---- every rank's kernel stores its pixels in place in rank 0's final images (rt_partition.in_place) ----
-        ring = min(max(total_frames, warmup * fpstep, N), max(3 * B, int(16e9 // frame_bytes)))
+        ring = min(max(total_frames, warmup * fpstep, N), max(2 * B, int(32e9 // frame_bytes)))
         ring = max(B, ring // B * B)                 # whole launches: a launch never straddles the wrap
         shared, direct = share_from_rank0(lambda: [torch.zeros((ring, HEIGHT, WIDTH, 3), dtype=torch.float32, device="cuda")])
         if direct:
