@@ -32,6 +32,16 @@
 namespace rtd {
 
 #define RT_BLOCK 256
+// Cost probes (diagnostics builds only, -DRT_DUP_BLOCK=n): block n of the FAST round body is executed twice on laundered
+// inputs, its second result kept alive but unused, so the slow-down of the build IS that block's cost at the kernel's real
+// occupancy and divergence.  1 scan  2 diffuse scatter direction  3 open-hit geometry  4 primary ray  5 two PCG draws
+#ifdef RT_DUP_BLOCK
+#define RT_DUP_IS(n) (RT_DUP_BLOCK == (n))
+#else
+#define RT_DUP_IS(n) false
+#endif
+#define RT_LAUNDER3(v) asm volatile("" : "+v"((v).x), "+v"((v).y), "+v"((v).z))
+#define RT_KEEP3(v) asm volatile("" ::"v"((v).x), "v"((v).y), "v"((v).z))
 #define RT_NF 16             // dwords per saved recursion level
 #define RT_QHEAD 13          // dwords of a parked path before its current level
 #define RT_INVALID 0xFFFFFFFFu
@@ -769,14 +779,33 @@ __global__ __launch_bounds__(RT_BLOCK, RT_WAVES_PER_EU) void k_pass(const PassPa
                 if (lvl == 0u) {
                     // the level-0 ray of sample samp-1 (imagetracer.rs:52-56, :67-75)
                     ColdParams C = cold_params();
+                    if (RT_DUP_IS(4)) {
+                        uint64_t m2 = mstate;
+                        asm volatile("" : "+v"(m2));
+                        Vec3 o2, d2;
+                        primary_ray<AFFINE>(C, frame_entry(C, px_fr), px_row, px_col, samp - 1u, m2, o2, d2);
+                        RT_KEEP3(o2); RT_KEEP3(d2);
+                    }
                     primary_ray<AFFINE>(C, frame_entry(C, px_fr), px_row, px_col, samp - 1u, mstate, o, d);
                     tmin = 1e-5f;                                   // Ray::default (ray.rs:50)
                 } else {
                     // BRDF::scatter_ray of the next child of the open hit (render.rs:160-166)
                     const float rf0 = pcg_random_float(st, pinc);
                     const float rf1 = pcg_random_float(st, pinc);
+                    if (RT_DUP_IS(5)) {
+                        uint64_t s2 = st;
+                        asm volatile("" : "+v"(s2));
+                        const float a2 = pcg_random_float(s2, pinc), b2 = pcg_random_float(s2, pinc);
+                        asm volatile("" ::"v"(a2), "v"(b2), "v"(s2));
+                    }
                     if (cur_brdf == RT_BRDF_DIFFUSE) {
                         d = diffuse_scatter_dir(rf0, rf1, cv);
+                        if (RT_DUP_IS(2)) {
+                            Vec3 n2 = cv;
+                            RT_LAUNDER3(n2);
+                            const Vec3 d2 = diffuse_scatter_dir(rf0, rf1, n2);
+                            RT_KEEP3(d2);
+                        }
                         tmin = 1.0e-3f;                             // material.rs:181
                     } else {
                         d = cv;
@@ -788,6 +817,14 @@ __global__ __launch_bounds__(RT_BLOCK, RT_WAVES_PER_EU) void k_pass(const PassPa
                 float t;
                 Vec3 lo, ld;
                 uint32_t bkind;
+                if (RT_DUP_IS(1)) {
+                    Vec3 o2 = o, d2 = d, lo2, ld2;
+                    RT_LAUNDER3(o2); RT_LAUNDER3(d2);
+                    float t2; uint32_t k2;
+                    const int b2 = closest_hit(o2, d2, tmin, __builtin_inff(), t2, lo2, ld2, k2);
+                    RT_KEEP3(lo2); RT_KEEP3(ld2);
+                    asm volatile("" ::"v"(t2), "v"(b2), "v"(k2));
+                }
                 const int best = closest_hit(o, d, tmin, __builtin_inff(), t, lo, ld, bkind);
                 RT_DBG_MARK(2);
                 bool leaf = true;
@@ -876,6 +913,20 @@ __global__ __launch_bounds__(RT_BLOCK, RT_WAVES_PER_EU) void k_pass(const PassPa
                                 const uint32_t nbrdf = sflags & 1u;
                                 // every child of a mirror hit has the same direction (material.rs:225-246)
                                 const Vec3 ncv = (nbrdf == RT_BRDF_SPECULAR) ? specular_scatter_dir(d, nrm) : nrm;
+                                if (RT_DUP_IS(3)) {
+                                    float hx2 = hx, hy2 = hy, hz2 = hz;
+                                    asm volatile("" : "+v"(hx2), "+v"(hy2), "+v"(hz2));
+                                    const Rows3 MW2 = load_rows(mrows[best].m);
+                                    const Rows3 IW2 = load_rows(scan[best].inv);
+                                    const Vec3 wp2 = rows_point<AFFINE>(MW2, AFFINE ? nullptr : g_wrows[best].m_w, hx2, hy2, hz2);
+                                    float nx2, ny2, nz2, dp2;
+                                    if (sphere) { dp2 = hx2 * ld.x + hy2 * ld.y + hz2 * ld.z; nx2 = hx2; ny2 = hy2; nz2 = hz2; }
+                                    else { dp2 = 0.0f * ld.x + 0.0f * ld.y + 1.0f * ld.z; nx2 = 0.0f; ny2 = 0.0f; nz2 = 1.0f; }
+                                    if (!(dp2 < 0.0f)) { nx2 = -nx2; ny2 = -ny2; nz2 = -nz2; }
+                                    const Vec3 nrm2 = rows_normal(IW2, nx2, ny2, nz2);
+                                    const Vec3 ncv2 = (nbrdf == RT_BRDF_SPECULAR) ? specular_scatter_dir(d, nrm2) : nrm2;
+                                    RT_KEEP3(wp2); RT_KEEP3(ncv2);
+                                }
                                 RT_DBG_MARK(9);
                                 if (lvl > 0u) {
                                     kcount += 1u;                   // this child of the level that is saved
