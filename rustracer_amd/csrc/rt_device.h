@@ -227,12 +227,48 @@ __device__ __forceinline__ Vec3 rows_normal(const Rows3& I, float x, float y, fl
     return r;
 }
 
+// ---------------------------------------------------------------------------------------------
+// Diagonal inverse matrices (every shape a composition of scalings and translations: rows 0..2 of invm are
+// [a 0 0 tx], [0 b 0 ty], [0 0 c tz] with exact zeros).  The reference still evaluates the full products
+// ((m0*x + m1*y) + m2*z) + m3 (src/transformation.rs:133-195); with finite operands the two zero terms are signed
+// zeros, and adding a signed zero changes nothing unless the other operand is itself a zero.  So a*x + t equals the
+// full expression bit for bit unless a*x and t are both zeros, where only the SIGN of the resulting zero can differ;
+// likewise a*d equals the full direction component unless it is a zero.  diag_ray_ok() admits only rays whose
+// direction components are all non-zero (|d_k| in [2^-60, 2^60]; the host checks |a|, |b|, |c| in the same range, so
+// no product underflows to zero) and whose origin is finite and bounded.  Then d'_k != 0 exactly as in the reference,
+// and a zero o'_k of either sign is harmless: a, c, delta and the roots do not see it (squares; b only if every
+// term is a zero, and then -b -/+ sqrt(delta) absorbs it), the plane's t = -/+0 is rejected by t <= tmin for any
+// tmin >= 0 either way, and the hit point o'_k + d'_k * t is the non-zero d'_k * t (t > tmin > 0, no underflow:
+// >= 2^-120 * tmin).  Every decision and every value that leaves the scan is therefore identical.
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ bool diag_ray_ok(Vec3 o, Vec3 d) {
+    const float lim = 0x1.0p60f, tiny = 0x1.0p-60f;
+    const float so = __builtin_fabsf(o.x) + __builtin_fabsf(o.y) + __builtin_fabsf(o.z);   // NaN / inf propagate
+    const float sd = __builtin_fabsf(d.x) + __builtin_fabsf(d.y) + __builtin_fabsf(d.z);
+    const float mn = __builtin_fminf(__builtin_fminf(__builtin_fabsf(d.x), __builtin_fabsf(d.y)), __builtin_fabsf(d.z));
+    return (so <= lim) && (sd <= lim) && (mn >= tiny);
+}
+__device__ __forceinline__ Vec3 rows_point_diag(const Rows3& R, float x, float y, float z) {
+    Vec3 r;
+    r.x = R.r0.x * x + R.r0.w;
+    r.y = R.r1.y * y + R.r1.w;
+    r.z = R.r2.z * z + R.r2.w;
+    return r;
+}
+__device__ __forceinline__ Vec3 rows_vector_diag(const Rows3& R, float x, float y, float z) {
+    Vec3 r;
+    r.x = R.r0.x * x;
+    r.y = R.r1.y * y;
+    r.z = R.r2.z * z;
+    return r;
+}
+
 // World::ray_intersection (src/world.rs:32-50) over a DScan table that every lane reads at the same
 // index (LDS broadcast or scalar loads): linear scan in insertion order, strict `<`, so the earliest
 // shape wins ties and the first hit is taken unconditionally (even t = NaN).  G shapes per iteration
 // (the loads of a group are issued together), no control flow inside a shape test; also returns the
 // winner's object-space ray and kind.
-template <bool AFFINE, int G>
+template <bool AFFINE, int G, bool DIAG = false>
 __device__ __forceinline__ int scan_closest_hit_g(const DScan* __restrict__ scan, const DWRows* __restrict__ wrows,
                                                   uint32_t n_shapes, Vec3 ro, Vec3 rd, float tmin, float tmax,
                                                   float& best_t, Vec3& best_o, Vec3& best_d, uint32_t& best_kind) {
@@ -253,8 +289,9 @@ __device__ __forceinline__ int scan_closest_hit_g(const DScan* __restrict__ scan
 #pragma unroll
         for (int g = 0; g < G; ++g) {
             const uint32_t i = (i0 + g < n_shapes) ? i0 + g : n_shapes - 1u;
-            const Vec3 o = rows_point<AFFINE>(R[g], AFFINE ? nullptr : wrows[i].inv_w, ro.x, ro.y, ro.z);
-            const Vec3 d = rows_vector(R[g], rd.x, rd.y, rd.z);
+            const Vec3 o = DIAG ? rows_point_diag(R[g], ro.x, ro.y, ro.z)
+                                : rows_point<AFFINE>(R[g], AFFINE ? nullptr : wrows[i].inv_w, ro.x, ro.y, ro.z);
+            const Vec3 d = DIAG ? rows_vector_diag(R[g], rd.x, rd.y, rd.z) : rows_vector(R[g], rd.x, rd.y, rd.z);
             float t = 0.0f;
             bool hit;
             if (kind[g] == RT_SHAPE_SPHERE) hit = sphere_t_nb(o, d, tmin, tmax, t);

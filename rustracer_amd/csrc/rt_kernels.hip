@@ -84,6 +84,7 @@ static_assert(sizeof(FrameEntry) == 96, "FrameEntry layout");
 // Everything a pass needs, passed by value (kernarg -> SGPRs).
 struct PassParams {
     uint32_t n_shapes;
+    uint32_t scene_diag;             // every shape's invm is affine with a diagonal 3x3 in [2^-60, 2^60] (see diag_ray_ok)
     uint32_t mode;                   // 0: image render; 1: batch Renderer::solve on caller (ray, pcg)
     // frames of this launch (mode 0): item id = frame * n_per_frame + local pixel
     const FrameEntry* frames;        // device table, or NULL: the frames are in frames_inline
@@ -461,6 +462,12 @@ __global__ __launch_bounds__(RT_BLOCK, RT_WAVES_PER_EU) void k_pass(const PassPa
                            uint32_t& bkind) -> int {
         if constexpr (!SCENE_LDS) {
             if (P.bvh.n_nodes != 0u) return bvh_closest_hit<AFFINE>(P.bvh, g_scan, g_wrows, P.n_shapes, o, d, tmin, tmax, t, lo, ld, bkind);
+        }
+        if constexpr (FAST && AFFINE) {
+            // scalings and translations only: the sparse form of the same arithmetic, when every live lane's ray qualifies
+            // (tmin is 1e-5 or 1e-3 here)
+            if (P.scene_diag != 0u && __ballot(busy && !diag_ray_ok(o, d)) == 0ull)
+                return scan_closest_hit_g<AFFINE, RT_SCAN_GROUP, true>(scan, g_wrows, P.n_shapes, o, d, tmin, tmax, t, lo, ld, bkind);
         }
         return scan_closest_hit_g<AFFINE, RT_SCAN_GROUP>(scan, g_wrows, P.n_shapes, o, d, tmin, tmax, t, lo, ld, bkind);
     };
@@ -1354,6 +1361,8 @@ __global__ __launch_bounds__(RT_BLOCK) void k_simple(const PassParams P, const D
             int best;
             if (!SCENE_LDS && P.bvh.n_nodes != 0u)
                 best = bvh_closest_hit<AFFINE>(P.bvh, g_scan, g_wrows, P.n_shapes, o, d, 1e-5f, __builtin_inff(), t, lo, ld, bkind);
+            else if (AFFINE && P.scene_diag != 0u && __ballot(!diag_ray_ok(o, d)) == 0ull)
+                best = scan_closest_hit_g<AFFINE, RT_SCAN_GROUP, true>(scan, g_wrows, P.n_shapes, o, d, 1e-5f, __builtin_inff(), t, lo, ld, bkind);
             else
                 best = scan_closest_hit_g<AFFINE, RT_SCAN_GROUP>(scan, g_wrows, P.n_shapes, o, d, 1e-5f, __builtin_inff(), t, lo, ld, bkind);
             if (best < 0) {

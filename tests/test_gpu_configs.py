@@ -240,3 +240,36 @@ def test_in_place_parts_assemble_in_one_image():
     torch.cuda.synchronize()
     for k in range(n_frames):
         assert_bit_equal(images[k].cpu().numpy(), ref, f"rotating blocks in place, frame {k}")
+
+
+def test_diagonal_inverse_specialisation_and_its_guard():
+    """Scenes made of scalings and translations take the sparse form of the closest-hit arithmetic (rt_device.h:
+    diag_ray_ok); it must equal the reference bit for bit, and rays it cannot prove that for -- a direction component of
+    exactly zero, far-away origins -- must fall back to the full products.  Negative and extreme scale factors included."""
+    world = ra.World()
+    sky = ra.Material(ra.DiffuseBRDF(ra.UniformPigment(ra.BLACK)), ra.UniformPigment((1.0, 0.9, 0.5)))
+    ground = ra.Material(ra.DiffuseBRDF(ra.CheckeredPigment((0.3, 0.5, 0.1), (0.1, 0.2, 0.5), 4)), ra.UniformPigment(ra.BLACK))
+    blue = ra.Material(ra.DiffuseBRDF(ra.UniformPigment((0.3, 0.4, 0.8))), ra.UniformPigment(ra.BLACK))
+    mirror = ra.Material(ra.SpecularBRDF(ra.UniformPigment((0.6, 0.2, 0.3))), ra.UniformPigment(ra.BLACK))
+    world.add(ra.Sphere(ra.scaling((150.0, 150.0, 150.0)), sky))
+    world.add(ra.Plane(ra.translation((0.0, 0.0, -0.5)), ground))
+    world.add(ra.Sphere(ra.translation((0.0, 0.0, 0.0)) * ra.scaling((-0.7, 0.4, 1.3)), blue))        # negative scale, ellipsoid
+    world.add(ra.Sphere(ra.translation((1.0, 1.5, 0.2)) * ra.scaling((0.5, 0.5, 0.5)), mirror))
+    world.add(ra.Sphere(ra.translation((0.5, -1.5, 0.0)) * ra.scaling((1e-3, 2.0, 0.25)), blue))      # thin
+    rr = ra.PathTracer(world, ra.BLACK, 5, 3, 2)
+    w, h = 96, 64
+    cams = [ra.PerspectiveCamera(1.0, 1.5, ra.translation((-3.0, 0.0, 0.4))),                # generic rays: the sparse form
+            ra.OrthogonalCamera(1.5, ra.translation((-3.0, 0.0, 0.0))),                      # d = (1, 0, 0): zero components
+            ra.PerspectiveCamera(1.0, 1.5, ra.translation((-2.0e18, 0.0, 0.4))),             # origin beyond the guard's bound
+            ra.PerspectiveCamera(1.0, 1.5, ra.rotation_z(0.3) * ra.translation((-3.0, 0.0, 0.4)))]
+    for cam in cams:
+        ref, rs = oracle(world, cam, rr, w, h)
+        for schedule in [(0,), ()]:
+            g, gs = gpu_render(world, cam, rr, w, h, schedule=schedule)
+            assert_bit_equal(g.cpu().numpy(), ref, f"diagonal scene, {type(cam).__name__}, schedule={schedule}")
+            for k in COUNTERS:
+                assert gs[k] == rs[k], (k, gs[k], rs[k])
+        fl = ra.FlatRenderer(world, ra.BLACK)
+        ref2, _ = oracle(world, cam, fl, w, h, aa=2)
+        g2, _ = gpu_image(world, cam, fl, w, h, aa=2)
+        assert_bit_equal(g2, ref2, f"diagonal scene, flat, {type(cam).__name__}")
