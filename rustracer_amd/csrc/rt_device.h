@@ -347,7 +347,8 @@ struct DBvh {
 template <bool AFFINE>
 __device__ __forceinline__ int bvh_closest_hit(const DBvh B, const DScan* __restrict__ scan, const DWRows* __restrict__ wrows,
                                                uint32_t n_shapes, Vec3 ro, Vec3 rd, float tmin, float tmax,
-                                               float& best_t, Vec3& best_o, Vec3& best_d, uint32_t& best_kind) {
+                                               float& best_t, Vec3& best_o, Vec3& best_d, uint32_t& best_kind,
+                                               const bool diag = false /* wave-uniform: sparse form allowed (diag_ray_ok) */) {
     const bool finite = (__builtin_fabsf(ro.x) < __builtin_inff()) && (__builtin_fabsf(ro.y) < __builtin_inff()) &&
                         (__builtin_fabsf(ro.z) < __builtin_inff()) && (__builtin_fabsf(rd.x) < __builtin_inff()) &&
                         (__builtin_fabsf(rd.y) < __builtin_inff()) && (__builtin_fabsf(rd.z) < __builtin_inff());
@@ -362,8 +363,14 @@ __device__ __forceinline__ int bvh_closest_hit(const DBvh B, const DScan* __rest
     auto test_shape = [&](uint32_t i) {
         const Rows3 R = load_rows(scan[i].inv);
         const uint32_t kind = scan[i].kind;
-        const Vec3 o = rows_point<AFFINE>(R, AFFINE ? nullptr : wrows[i].inv_w, ro.x, ro.y, ro.z);
-        const Vec3 d = rows_vector(R, rd.x, rd.y, rd.z);
+        Vec3 o, d;
+        if (AFFINE && diag) {
+            o = rows_point_diag(R, ro.x, ro.y, ro.z);
+            d = rows_vector_diag(R, rd.x, rd.y, rd.z);
+        } else {
+            o = rows_point<AFFINE>(R, AFFINE ? nullptr : wrows[i].inv_w, ro.x, ro.y, ro.z);
+            d = rows_vector(R, rd.x, rd.y, rd.z);
+        }
         float t = 0.0f;
         bool hit;
         if (kind == RT_SHAPE_SPHERE) hit = sphere_t_nb(o, d, tmin, tmax, t);

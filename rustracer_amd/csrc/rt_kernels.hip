@@ -461,12 +461,16 @@ __global__ __launch_bounds__(RT_BLOCK, RT_WAVES_PER_EU) void k_pass(const PassPa
     auto closest_hit = [&](const Vec3 o, const Vec3 d, const float tmin, const float tmax, float& t, Vec3& lo, Vec3& ld,
                            uint32_t& bkind) -> int {
         if constexpr (!SCENE_LDS) {
-            if (P.bvh.n_nodes != 0u) return bvh_closest_hit<AFFINE>(P.bvh, g_scan, g_wrows, P.n_shapes, o, d, tmin, tmax, t, lo, ld, bkind);
+            if (P.bvh.n_nodes != 0u) {
+                // image renders trace with tmin 1e-5 / 1e-3 (>= 0, as the sparse form's proof needs); batch solves bring their own
+                const bool dg = AFFINE && P.scene_diag != 0u && K_MODE == 0u && __ballot(!diag_ray_ok(o, d)) == 0ull;
+                return bvh_closest_hit<AFFINE>(P.bvh, g_scan, g_wrows, P.n_shapes, o, d, tmin, tmax, t, lo, ld, bkind, dg);
+            }
         }
         if constexpr (FAST && AFFINE) {
             // scalings and translations only: the sparse form of the same arithmetic, when every live lane's ray qualifies
             // (tmin is 1e-5 or 1e-3 here)
-            if (P.scene_diag != 0u && __ballot(busy && !diag_ray_ok(o, d)) == 0ull)
+            if (P.scene_diag != 0u && __ballot(!diag_ray_ok(o, d)) == 0ull)
                 return scan_closest_hit_g<AFFINE, RT_SCAN_GROUP, true>(scan, g_wrows, P.n_shapes, o, d, tmin, tmax, t, lo, ld, bkind);
         }
         return scan_closest_hit_g<AFFINE, RT_SCAN_GROUP>(scan, g_wrows, P.n_shapes, o, d, tmin, tmax, t, lo, ld, bkind);
