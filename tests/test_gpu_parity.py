@@ -605,7 +605,9 @@ def test_random_scenes():
     # seeds from a million on add extreme transforms (huge, tiny, flat: infinite / NaN matrices) and colours; the listed
     # ones had a plane hit at t = NaN that the hierarchy ordered differently from the linear scan
     seeds = list(range(1000, 1060)) + list(range(1000000, 1000060)) + [1000076, 1000165, 1000221, 1000347, 1000651] + \
-        list(range(2000000, 2000030))       # ... and from two million on: negative / huge / infinite / NaN colours
+        list(range(2000000, 2000030)) + \
+        list(range(3000000, 3000040))       # ... two million on: negative / huge / infinite / NaN colours; three million on: worlds of
+                                            # scalings and translations only (the sparse closest-hit form and its ray guard)
     import warnings
     for seed in seeds:
         with warnings.catch_warnings():

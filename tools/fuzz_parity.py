@@ -32,11 +32,15 @@ def random_pigment(rng, tex, bright=1.0, nasty=False):
     return ra.ImagePigment(tex)
 
 
-def random_transform(rng, spread, rmin, rmax, projective=False, nasty=False):
+def random_transform(rng, spread, rmin, rmax, projective=False, nasty=False, axis=False):
     c = tuple(float(x) for x in rng.uniform(-spread, spread, 3))
+    if axis and rng.random() < 0.3:
+        c = tuple(float(round(x)) if rng.random() < 0.5 else x for x in c)      # exact zeros and integers among the translations
     r = float(rng.uniform(rmin, rmax))
+    if axis and rng.random() < 0.3:
+        r = -r                                                                   # mirrored shapes
     t = ra.translation(c)
-    if rng.random() < 0.6:
+    if not axis and rng.random() < 0.6:
         t = t * ra.rotation_z(float(rng.uniform(0, 360))) * ra.rotation_y(float(rng.uniform(0, 360))) * \
             ra.rotation_x(float(rng.uniform(0, 360)))
     if rng.random() < 0.5:
@@ -75,6 +79,8 @@ def random_case(seed):
     rng = np.random.default_rng(seed)
     nasty = seed >= 1_000_000           # seeds from a million on also draw extreme transforms and backgrounds,
     nasty2 = seed >= 2_000_000          # from two million on extreme colours and checker steps as well
+    axis = seed >= 3_000_000            # from three million on: scalings and translations only (the sparse closest-hit form
+                                        # and its guard), cameras without rotation half of the time (zero direction components)
     tex = ra.HdrImage(int(rng.integers(1, 9)), int(rng.integers(1, 9)))
     tex.pixels = rng.uniform(0, 1, (tex.height, tex.width, 3)).astype(np.float32)
     size_class = int(rng.integers(0, 4))
@@ -90,16 +96,18 @@ def random_case(seed):
         mat = ra.Material(brdf, emit)
         u = rng.random()
         if u < 0.08:
-            world.add(ra.Plane(random_transform(rng, spread, 0.5, 2.0, nasty=nasty), mat))
-        elif u < 0.11:
+            world.add(ra.Plane(random_transform(rng, spread, 0.5, 2.0, nasty=nasty, axis=axis), mat))
+        elif u < 0.11 and not axis:
             world.add(ra.Sphere(random_transform(rng, spread, 0.3, 1.5, projective=True, nasty=nasty), mat))
         else:
-            world.add(ra.Sphere(random_transform(rng, spread, 0.2, 1.8, nasty=nasty), mat))
+            world.add(ra.Sphere(random_transform(rng, spread, 0.2, 1.8, nasty=nasty, axis=axis), mat))
         if rng.random() < 0.03 and len(world.shapes) < n_shapes:
             world.add(world.shapes[-1])          # exact duplicate: the earlier index wins (world.rs:38)
     w, h = int(rng.integers(1, 97)), int(rng.integers(1, 65))
     cam_t = ra.translation(tuple(float(x) for x in rng.uniform(-4, 4, 3))) * ra.rotation_z(float(rng.uniform(0, 360))) * \
         ra.rotation_y(float(rng.uniform(-40, 40)))
+    if axis and rng.random() < 0.5:
+        cam_t = ra.translation(tuple(float(x) for x in rng.uniform(-4, 4, 3)))
     aspect = w / h if rng.random() < 0.7 else float(rng.uniform(0.5, 2.5))
     if rng.random() < 0.75:
         cam = ra.PerspectiveCamera(float(rng.uniform(0.4, 3.0)), aspect, cam_t)
