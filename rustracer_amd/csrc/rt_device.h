@@ -338,10 +338,11 @@ struct __attribute__((aligned(16))) DBvhNode {
 static_assert(sizeof(DBvhNode) == 48, "DBvhNode layout");
 
 struct DBvh {
-    const DBvhNode* nodes;
+    const DBvhNode* nodes;       // n_nodes, or 8 * n_nodes: the tree laid out once per sign octant of the ray direction (near half first)
     const uint32_t* leaf_shapes;
     const uint32_t* unbounded;   // shapes outside the hierarchy, ascending
     uint32_t n_nodes, n_unbounded;
+    uint32_t by_octant;          // 1: `nodes` holds the 8 layouts; 0: one layout (small trees: 8 copies would only thrash the L1)
 };
 
 template <bool AFFINE>
@@ -400,10 +401,12 @@ __device__ __forceinline__ int bvh_closest_hit(const DBvh B, const DScan* __rest
     // "while-while" traversal: every lane walks inner nodes until it stands on a leaf whose box it passes (or is
     // done), then the wave runs the shape tests of all those leaves together -- a lane's leaf visits are few, so
     // the expensive tests execute a few times per ray instead of once per node step of the slowest lane.
-    uint32_t i = 0;
+    const uint32_t octant = B.by_octant ? ((rd.x < 0.0f ? 1u : 0u) | (rd.y < 0.0f ? 2u : 0u) | (rd.z < 0.0f ? 4u : 0u)) : 0u;
+    uint32_t i = octant * B.n_nodes;                 // this ray's near-to-far layout: nodes [i, i_end) of the concatenated array
+    const uint32_t i_end = i + B.n_nodes;
     for (;;) {
       uint32_t leaf_first = 0, leaf_count = 0;
-      while (i < B.n_nodes) {
+      while (i < i_end) {
         const float4* np = reinterpret_cast<const float4*>(B.nodes + i);
         const float4 n0 = np[0], n1 = np[1], n2 = np[2];
         // D: distance to the farthest corner of the box; (|o| + |c|)^2 <= 2 |o|^2 + 2 |c|^2 with c its farthest corner
