@@ -175,10 +175,13 @@ def test_world_ray_intersection_random_rays():
     assert sum(h.hit for h in g) > 1000
 
 
-def test_hierarchy_returns_the_linear_scans_winner_on_adversarial_rays():
+@pytest.mark.parametrize("octants", ["0", "1"])
+def test_hierarchy_returns_the_linear_scans_winner_on_adversarial_rays(octants, monkeypatch):
     """Scenes of more than 96 shapes are traversed through the exact-winner hierarchy (rt_device.h): every hit
     record must equal the oracle's linear scan, also where the f32 discriminant is mostly rounding error
-    (far origins, tiny far spheres, grazing rays), on ties (duplicates) and for unbounded / projective shapes."""
+    (far origins, tiny far spheres, grazing rays), on ties (duplicates) and for unbounded / projective shapes.
+    Both with one layout of the tree and with the eight near-to-far layouts large worlds get."""
+    monkeypatch.setenv("RUSTRACER_BVH_OCTANTS", octants)
     rng = np.random.default_rng(11)
     world = ra.World()
     world.add(ra.Sphere(ra.scaling((400, 400, 400))))                       # everything is inside this one
@@ -620,6 +623,23 @@ def test_random_scenes():
                 fuzz_parity.check_frames(seed, case)
         except AssertionError as e:
             raise AssertionError(f"seed {seed} ({fuzz_parity.describe(*case)}): {e}") from e
+    # worlds that go through the hierarchy once more, with the eight near-to-far layouts forced (by themselves only
+    # trees beyond 16 KiB of nodes get them)
+    os.environ["RUSTRACER_BVH_OCTANTS"] = "1"
+    try:
+        for seed in seeds:
+            with warnings.catch_warnings():
+                warnings.simplefilter("ignore")
+                case = fuzz_parity.random_case(seed)
+            if len(case[0].shapes) <= 96:
+                continue
+            try:
+                fuzz_parity.check_case(seed, case)
+                fuzz_parity.check_batch(seed, case)
+            except AssertionError as e:
+                raise AssertionError(f"seed {seed}, octant layouts ({fuzz_parity.describe(*case)}): {e}") from e
+    finally:
+        del os.environ["RUSTRACER_BVH_OCTANTS"]
 
 
 def test_render_frames_animation_in_one_launch():
