@@ -118,7 +118,48 @@ def cpu_baseline(flat, cam, rr, w, h, aa, gpu_frame):
     return out, outl
 
 
+def remote_store_probe_child(argv):
+    """`bench.py --probe-remote-store DEVICE WIDTH HEIGHT ROW` (started by a rank of the N > 1 run, rank 0's pickled IPC
+    handle on stdin): map rank 0's images, let THIS device's render kernel store one image row in place through the
+    mapping, read it back and compare it with the same row rendered locally.  Exit status 0 = kernels of this device can
+    store into rank 0's memory.  A fault here ends this child, not the rank that asked."""
+    import pickle
+    import torch
+    import rustracer_amd as ra
+    from rustracer_amd import _abi, scenes
+    from rustracer_amd.world import flatten_camera
+    device, w, h, row = (int(x) for x in argv[:4])
+    if os.environ.get("RUSTRACER_BENCH_FAIL_PROBE"):  # tests: the fallback to copies
+        sys.exit(9)
+    torch.cuda.set_device(device)
+    fn, a = pickle.load(sys.stdin.buffer)
+    images = fn(*a)                                   # (ring, h, w, 3) on rank 0's device
+    lib = _abi.lib()
+    _abi.check(lib.rt_init(device))
+    scene = scenes.demo_world()
+    cam = flatten_camera(scenes.demo_camera(w, h))
+    rr = ra.PathTracer(scene, ra.BLACK, 2, 2, 1).flatten()
+    dev = scene.device()
+    dev.set_schedule((0,))
+    part = _abi.rt_partition(row, h, 1, 0, 1)         # 1-row tiles dealt over h parts: part `row` is exactly image row `row`
+    local = torch.zeros((h, w, 3), dtype=torch.float32, device="cuda")
+    st = torch.cuda.current_stream().cuda_stream
+    cams = (_abi.rt_camera * 1)(cam)
+    for target in (local, images[0]):
+        _abi.check(lib.rt_render_frames(dev.handle, cams, 1, C.byref(rr), w, h, INIT_STATE, INIT_SEQ, 1, C.byref(part),
+                                        (C.c_void_p * 1)(target.data_ptr()), st, None))
+    torch.cuda.synchronize()
+    got = images[0][row].to("cpu")
+    want = local[row].to("cpu")
+    if not torch.equal(got.view(torch.int32), want.view(torch.int32)) or float(want.abs().sum()) == 0.0:
+        print("remote-store probe: the row read back through the mapping differs from the local render", file=sys.stderr)
+        sys.exit(3)
+    sys.exit(0)
+
+
 def main():
+    if len(sys.argv) > 1 and sys.argv[1] == "--probe-remote-store":
+        remote_store_probe_child(sys.argv[2:])
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=0, help="default: 240 (c3), 1 (c4, c5)")
@@ -236,8 +277,13 @@ def main():
     if N > 1:
         cpu_group = dist.new_group(backend="gloo") if args.dist_backend == "nccl" else dist.group.WORLD
 
-    def share_from_rank0(make):
-        """rank 0 allocates tensors and shares them through HIP IPC handles; returns (local-or-mapped tensors, ok)."""
+    def share_from_rank0(make, kernel_stores=False):
+        """rank 0 allocates tensors and shares them through HIP IPC handles; returns (local-or-mapped tensors, ok).
+        kernel_stores: the mapping will be written by this rank's render kernels, not by copies: try that first in a child
+        process (remote_store_probe_child), so that a GPU fault on a platform where it does not work costs the child and
+        the run falls back to copies."""
+        import pickle
+        import subprocess
         from torch.multiprocessing.reductions import reduce_tensor
         ok, box, mine = 1, [None], None
         if rank == 0:
@@ -257,6 +303,12 @@ def main():
                     probe = torch.zeros(1, dtype=torch.float32, device="cuda")
                     mine[0].view(-1)[:1].copy_(probe)        # a first write through the mapping, checked here
                     torch.cuda.synchronize()
+                    if kernel_stores:
+                        p = subprocess.run([sys.executable, os.path.abspath(__file__), "--probe-remote-store", str(device),
+                                            str(WIDTH), str(HEIGHT), str(HEIGHT // 2 + rank)], input=pickle.dumps(box[0][0]),
+                                           capture_output=True, timeout=300)
+                        if p.returncode != 0:
+                            raise RuntimeError(f"remote-store probe exited {p.returncode}: {p.stderr.decode(errors='replace')[-400:]}")
                 except Exception as e:   # noqa: BLE001
                     print(f"p2p gather unavailable on rank {rank}: {e}", file=sys.stderr)
                     ok = 0
@@ -272,10 +324,12 @@ def main():
         # ---- every rank's kernel stores its pixels in place in rank 0's final images (rt_partition.in_place) ----
         ring = min(max(total_frames, warmup * fpstep, N), max(2 * B, int(32e9 // frame_bytes)))
         ring = max(B, ring // B * B)                 # whole launches: a launch never straddles the wrap
-        shared, direct = share_from_rank0(lambda: [torch.zeros((ring, HEIGHT, WIDTH, 3), dtype=torch.float32, device="cuda")])
+        shared, direct = share_from_rank0(lambda: [torch.zeros((ring, HEIGHT, WIDTH, 3), dtype=torch.float32, device="cuda")],
+                                          kernel_stores=True)
         if direct:
             images = shared[0]
         else:
+            shared = None
             args.gather = "p2p"
             F = max(1, min(args.inflight, 4)) if args.inflight else 2
             streams = [torch.cuda.Stream() for _ in range(F)]

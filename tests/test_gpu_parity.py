@@ -358,10 +358,10 @@ def test_c3_pathtracer_demo_small():
     assert st["rays"] > 192 * 108 * 10
 
 
-@pytest.mark.parametrize("n,d,rr", [(0, 3, 3), (4, 0, 0), (1, 2, 0), (4, 1, 5), (2, 4, 1), (7, 2, 2)])
+@pytest.mark.parametrize("n,d,rr", [(0, 3, 3), (4, 0, 0), (1, 2, 0), (4, 1, 5), (2, 4, 1), (7, 2, 2), (2, 7, 3), (1, 12, 9)])
 def test_pathtracer_parameter_corners_image(n, d, rr):
-    """num_of_rays 0, max_depth 0, roulette from depth 0 / never reached: through the latency schedule and
-    (check_image) the FAST variant."""
+    """num_of_rays 0, max_depth 0, roulette from depth 0 / never reached, recursions too deep for the LDS stack (max_depth
+    7 and 12: saved levels in HBM): through the latency schedule and (check_image) the FAST variant."""
     world = demo_world()
     check_image(world, demo_camera(96, 54), ra.PathTracer(world, (0.02, 0.03, 0.05), n, d, rr), 96, 54, init_state=9, init_seq=11)
 

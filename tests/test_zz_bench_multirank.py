@@ -40,3 +40,15 @@ def test_two_ranks_on_one_gpu_assemble_bit_identical_frames(scaling, gather):
     if gather == "p2p":
         assert ("p2p copies in place" if scaling == "weak" else "(p2p gather)") in r.stderr, r.stderr[-2000:]
     assert '"n_gpus": 2' in r.stdout and f'"scaling": "{scaling}"' in r.stdout
+
+
+def test_direct_stores_fall_back_to_copies_when_the_probe_fails():
+    """Before any rank's kernel stores through the mapping of rank 0's images, a child process tries it
+    (bench.remote_store_probe_child); when that child fails, the run must go on with device-to-device copies."""
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "4", "--warmup", "2",
+           "--repeats", "1", "--dist-backend", "gloo", "--verify"]
+    r = subprocess.run(cmd, cwd=ROOT, capture_output=True, text=True, timeout=280, env=dict(os.environ, RUSTRACER_BENCH_FAIL_PROBE="1"))
+    assert r.returncode == 0, r.stderr[-2000:]
+    assert "remote-store probe exited 9" in r.stderr, r.stderr[-2000:]
+    assert "verify ok" in r.stderr and "p2p copies in place" in r.stderr, r.stderr[-2000:]
