@@ -155,9 +155,15 @@ __device__ __forceinline__ float sqrt_rn(float x) {
 // ---------------------------------------------------------------------------------------------
 
 // Sphere::ray_intersection up to first_hit_t (src/shape.rs:112-133) and Plane::ray_intersection up to t
-// (src/shape.rs:196-204), the reference's values and decisions without control flow: the roots are
-// computed for every lane (sqrt of a negative delta is NaN and fails every comparison; delta <= 0 is
-// rejected explicitly; a NaN plane t passes both range tests exactly as in the reference).
+// (src/shape.rs:196-204), the reference's values and decisions (sqrt of a negative delta is NaN and fails every
+// comparison; delta <= 0 is rejected explicitly; a NaN plane t passes both range tests exactly as in the reference).
+//
+// One IEEE divide per sphere instead of the reference's two, same result: the reference takes t1 = n1 / (2a) if it lies
+// in (tmin, tmax), else t2 = n2 / (2a).  2a is +0, positive, +inf or NaN (a sum of squares), so with tmin >= 0 a
+// numerator n1 that is not > 0 gives a quotient that is <= 0, -inf or NaN and fails `t1 > tmin` whatever its rounding:
+// such lanes (every ray that starts inside the sphere, e.g. all rays against a sky sphere; every ray whose sphere lies
+// behind it) divide n2 straight away.  Lanes with n1 > 0 divide n1; the few whose t1 then falls outside (tmin, tmax)
+// divide again (a wave-level rarity).  A negative tmin (batch calls with the caller's rays) keeps the first root.
 __device__ __forceinline__ bool sphere_t_nb(Vec3 o, Vec3 d, float tmin, float tmax, float& t_out) {
     const float a = d.x * d.x + d.y * d.y + d.z * d.z;
     const float b = 2.0f * (o.x * d.x + o.y * d.y + o.z * d.z);
@@ -165,12 +171,16 @@ __device__ __forceinline__ bool sphere_t_nb(Vec3 o, Vec3 d, float tmin, float tm
     const float delta = b * b - 4.0f * a * c;
     const float sqrt_delta = sqrt_rn(delta);
     const float a2 = 2.0f * a;
-    const float t1 = (-b - sqrt_delta) / a2;
-    const float t2 = (-b + sqrt_delta) / a2;
-    const bool h1 = (t1 > tmin) && (t1 < tmax);
-    const bool h2 = (t2 > tmin) && (t2 < tmax);
-    t_out = h1 ? t1 : t2;
-    return (delta > 0.0f) && (h1 || h2);
+    const float n1 = -b - sqrt_delta, n2 = -b + sqrt_delta;
+    const bool first = (n1 > 0.0f) || !(tmin >= 0.0f);
+    float t = (first ? n1 : n2) / a2;
+    bool h = (t > tmin) && (t < tmax);
+    if (first && !h) {
+        t = n2 / a2;
+        h = (t > tmin) && (t < tmax);
+    }
+    t_out = t;
+    return (delta > 0.0f) && h;
 }
 __device__ __forceinline__ bool plane_t_nb(Vec3 o, Vec3 d, float tmin, float tmax, float& t_out) {
     const float t = -o.z / d.z;
