@@ -417,6 +417,9 @@ __device__ __forceinline__ int bvh_closest_hit(const DBvh B, const DScan* __rest
     for (;;) {
       uint32_t leaf_first = 0, leaf_count = 0;
       while (i < i_end) {
+        // the conservative node test is this library's own arithmetic, not the reference's: fused multiply-adds are welcome
+        // (every bound below carries a relative margin far above one rounding)
+#pragma clang fp contract(fast)
         const float4* np = reinterpret_cast<const float4*>(B.nodes + i);
         const float4 n0 = np[0], n1 = np[1], n2 = np[2];
         // D: distance to the farthest corner of the box; (|o| + |c|)^2 <= 2 |o|^2 + 2 |c|^2 with c its farthest corner
