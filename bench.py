@@ -9,13 +9,12 @@ N GPUs (one process per GPU, torch.distributed):
 
   weak (default for c3): a step is N frames, so every GPU keeps one frame's worth of work per step.  Every frame is
       split into N contiguous row blocks; frame f's block (rank + f) % N is rendered by `rank` (rt_partition.rotate), so
-      over N frames every GPU renders every block once and the blocks' unequal costs balance.  A block lands in rank 0's
-      final image with one plain device-to-device copy over xGMI (rank 0 shares its images through a HIP IPC handle; the
-      copies run on a copy stream beside the next launch's render); rank 0 renders its own blocks in place.  No unpack
-      kernel, no per-launch barrier.  Fallback when the handle cannot be exchanged (--gather rccl): one RCCL gather per
-      launch, blocks placed by rank 0.
+      over N frames every GPU renders every block once and the blocks' unequal costs balance.  Rank 0 shares its final
+      images through a HIP IPC handle and every rank's render kernel stores its pixels in place, across xGMI, beside the
+      render (--gather direct; tried first in a child process, see remote_store_probe_child).  Fallbacks: blocks rendered
+      locally and copied device-to-device into their place (--gather p2p), or one RCCL gather per launch (--gather rccl).
   strong (default for c4 / c5, whose single frames are seconds of work): every frame is split by 1-row tiles dealt
-      round-robin, the parts are pushed into rank 0's buffers and rt_unpack_parts assembles them.
+      round-robin and stored in place the same way (fallback: parts pushed into rank 0's buffers, rt_unpack_parts).
 
   python bench.py --gpus 1 --steps K --warmup W
   python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
