@@ -253,7 +253,8 @@ int rt_brdf_scatter_ray(uint32_t brdf, const float* rf, const float* incoming_di
                         const float* normal, uint32_t depth, uint64_t n, rt_ray* out);
 
 /* Evaluate include/rt_strict_math.h on the GPU (fn: 0 sin, 1 cos, 2 atan2(y=a,x=b), 3 acos,
- * 4 a/b, 5 sqrt(a) as the render kernels compute it, 6 its short form for a == 0 or a >= 2^-96);
+ * 4 a/b, 5 sqrt(a) as the render kernels compute it, 6 its short form for a == 0 or a >= 2^-96,
+ * 7 rt_maxf(a, b), 8 the bits of rt_f32_to_u32_sat(a));
  * used to prove host/device bit-equality of the shared math. */
 int rt_strict_math_eval(int fn, const float* a, const float* b, uint64_t n, float* out);
 

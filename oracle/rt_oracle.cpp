@@ -799,6 +799,8 @@ int oracle_math_eval(int fn, int math_mode, const float* a, const float* b, uint
             case 2: out[i] = mf.atan2(a[i], b[i]); break;
             case 3: out[i] = mf.acos(a[i]); break;
             case 4: out[i] = a[i] / b[i]; break;
+            case 7: out[i] = rt_maxf(a[i], b[i]); break;                     // the host body of the shared helper
+            case 8: { const uint32_t u = rt_f32_to_u32_sat(a[i]); std::memcpy(&out[i], &u, 4); break; }
             default: out[i] = std::sqrt(a[i]); break;
         }
     }

@@ -1472,6 +1472,8 @@ __global__ __launch_bounds__(RT_BLOCK) void k_math(int fn, const float* __restri
         case 4: r = a[i] / b[i]; break;
         case 5: r = sqrt_rn(a[i]); break;                 // the hot path's sqrt (rt_device.h)
         case 6: r = sqrt_rn_normal(a[i]); break;          // its short form: 0, or >= 2^-96
+        case 7: r = rt_maxf(a[i], b[i]); break;           // Rust f32::max (render.rs:148, :150)
+        case 8: r = __uint_as_float(rt_f32_to_u32_sat(a[i])); break;   // Rust `as u32`, the result's bits (material.rs:56-57, :88-89)
         default: r = __builtin_sqrtf(a[i]); break;
     }
     out[i] = r;

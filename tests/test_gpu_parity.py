@@ -124,6 +124,32 @@ def test_strict_math_host_device_bit_equal():
         assert_bit_equal(_gpu_math(6, (np.float32(1.0) - rf).astype(np.float32)), O.math_eval(5, (np.float32(1.0) - rf).astype(np.float32)), "sqrt(1 - rf)")
 
 
+def test_shared_header_helpers_against_an_independent_statement_of_rusts_semantics():
+    """rt_maxf and rt_f32_to_u32_sat live in the header the oracle shares with the kernels, so a bit-exact image test
+    cannot see a bug in them; here the device versions are checked against numpy's own statement of Rust's f32::max
+    (a NaN operand yields the other one) and of the saturating `as u32` cast (NaN -> 0)."""
+    rng = np.random.default_rng(11)
+    n = 1 << 16
+    specials = np.array([0.0, -0.0, 1.0, -1.0, np.inf, -np.inf, np.nan, 0.05, 1e-45, 3.4e38, 4294967296.0, 4294967040.0,
+                         2147483648.0, 0.99999994, -1e-45, 16777216.5], dtype=np.float32)
+    a = np.concatenate([np.repeat(specials, len(specials)), rng.normal(size=n).astype(np.float32)])
+    b = np.concatenate([np.tile(specials, len(specials)), rng.normal(size=n).astype(np.float32)])
+    got = _gpu_math(7, a, b)
+    with np.errstate(all="ignore"):
+        want = np.fmax(a, b)                    # IEEE maxNum: the non-NaN operand; NaN only if both are
+    both_zero = (a == 0) & (b == 0)             # max(+0, -0): either zero is a correct answer (and the renderers never see its sign)
+    assert np.array_equal(np.isnan(got), np.isnan(want))
+    ok = ~np.isnan(want) & ~both_zero
+    assert np.array_equal(got[ok].view(np.uint32), want[ok].view(np.uint32))
+    assert np.all(got[both_zero] == 0)
+    x = np.concatenate([specials, rng.uniform(-10, 5e9, n).astype(np.float32), rng.uniform(0, 300, n).astype(np.float32)])
+    got_u = _gpu_math(8, x).view(np.uint32)
+    with np.errstate(all="ignore"):
+        xd = x.astype(np.float64)
+        want_u = np.where(np.isnan(xd), 0.0, np.clip(np.trunc(xd), 0.0, 4294967295.0)).astype(np.uint64).astype(np.uint32)
+    assert np.array_equal(got_u, want_u)
+
+
 # ---- World::ray_intersection (src/shape.rs:223-568, src/world.rs:62-92) ------------------------
 def _rays(rng, n):
     rays = []

@@ -388,3 +388,29 @@ def test_oracle_modes_agree_on_demo_scene():
     bad = float(np.mean(rel.max(axis=2) > 1e-4))
     print(f"libm-vs-strict outlier pixel fraction: {bad:.5f}; rays {sa['rays']} vs {sb['rays']}")
     assert bad < 0.02
+
+
+def test_shared_header_helpers_host_side_against_rusts_semantics():
+    """The host bodies of rt_maxf / rt_f32_to_u32_sat (include/rt_strict_math.h) against numpy's own statement of Rust's
+    f32::max (a NaN operand yields the other operand) and of the saturating `as u32` cast (NaN -> 0); the GPU suite checks
+    the device bodies against the same statement (test_shared_header_helpers_against_an_independent_statement_...)."""
+    rng = np.random.default_rng(11)
+    n = 1 << 14
+    specials = np.array([0.0, -0.0, 1.0, -1.0, np.inf, -np.inf, np.nan, 0.05, 1e-45, 3.4e38, 4294967296.0, 4294967040.0,
+                         2147483648.0, 0.99999994, -1e-45, 16777216.5], dtype=np.float32)
+    a = np.concatenate([np.repeat(specials, len(specials)), rng.normal(size=n).astype(np.float32)])
+    b = np.concatenate([np.tile(specials, len(specials)), rng.normal(size=n).astype(np.float32)])
+    got = O.math_eval(7, a, b)
+    with np.errstate(all="ignore"):
+        want = np.fmax(a, b)
+    both_zero = (a == 0) & (b == 0)
+    assert np.array_equal(np.isnan(got), np.isnan(want))
+    ok = ~np.isnan(want) & ~both_zero
+    assert np.array_equal(got[ok].view(np.uint32), want[ok].view(np.uint32))
+    assert np.all(got[both_zero] == 0)
+    x = np.concatenate([specials, rng.uniform(-10, 5e9, n).astype(np.float32), rng.uniform(0, 300, n).astype(np.float32)])
+    got_u = O.math_eval(8, x).view(np.uint32)
+    with np.errstate(all="ignore"):
+        xd = x.astype(np.float64)
+        want_u = np.where(np.isnan(xd), 0.0, np.clip(np.trunc(xd), 0.0, 4294967295.0)).astype(np.uint64).astype(np.uint32)
+    assert np.array_equal(got_u, want_u)
