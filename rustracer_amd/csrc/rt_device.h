@@ -359,7 +359,9 @@ template <bool AFFINE>
 __device__ __forceinline__ int bvh_closest_hit(const DBvh B, const DScan* __restrict__ scan, const DWRows* __restrict__ wrows,
                                                uint32_t n_shapes, Vec3 ro, Vec3 rd, float tmin, float tmax,
                                                float& best_t, Vec3& best_o, Vec3& best_d, uint32_t& best_kind,
-                                               const bool diag = false /* wave-uniform: sparse form allowed (diag_ray_ok) */) {
+                                               const bool diag = false /* wave-uniform: sparse form allowed (diag_ray_ok) */,
+                                               const int cached = -2 /* per lane: -2 unknown; else the known answer to this very query
+                                                                        (-1 no hit, >= 0 the winning shape): only that shape is tested */) {
     const bool finite = (__builtin_fabsf(ro.x) < __builtin_inff()) && (__builtin_fabsf(ro.y) < __builtin_inff()) &&
                         (__builtin_fabsf(ro.z) < __builtin_inff()) && (__builtin_fabsf(rd.x) < __builtin_inff()) &&
                         (__builtin_fabsf(rd.y) < __builtin_inff()) && (__builtin_fabsf(rd.z) < __builtin_inff());
@@ -394,7 +396,12 @@ __device__ __forceinline__ int bvh_closest_hit(const DBvh B, const DScan* __rest
             best_kind = kind;
         }
     };
-    for (uint32_t u = 0; u < B.n_unbounded; ++u) test_shape(B.unbounded[u]);
+    // A lane that already knows the winner of this exact ray (the children of a mirror hit all trace the same ray,
+    // src/material.rs:225-246) skips the unbounded shapes and the traversal and re-runs the winner's own test at the end:
+    // the same inputs through the same arithmetic give the same t and object-space ray.
+    const bool walk = (cached == -2);
+    for (uint32_t u = 0; u < B.n_unbounded; ++u)
+        if (walk) test_shape(B.unbounded[u]);
     // Plane::ray_intersection reports a hit whose t is NaN (its two rejections are comparisons that NaN fails,
     // src/shape.rs:198-204); the linear scan then keeps that hit iff no earlier shape is hit at all, which is not
     // a minimum over (t, index).  Only unbounded shapes can do this: such a wave takes the linear scan.
@@ -412,8 +419,8 @@ __device__ __forceinline__ int bvh_closest_hit(const DBvh B, const DScan* __rest
     // done), then the wave runs the shape tests of all those leaves together -- a lane's leaf visits are few, so
     // the expensive tests execute a few times per ray instead of once per node step of the slowest lane.
     const uint32_t octant = B.by_octant ? ((rd.x < 0.0f ? 1u : 0u) | (rd.y < 0.0f ? 2u : 0u) | (rd.z < 0.0f ? 4u : 0u)) : 0u;
-    uint32_t i = octant * B.n_nodes;                 // this ray's near-to-far layout: nodes [i, i_end) of the concatenated array
-    const uint32_t i_end = i + B.n_nodes;
+    const uint32_t i_end = (octant + 1u) * B.n_nodes;
+    uint32_t i = walk ? octant * B.n_nodes : i_end;  // this ray's near-to-far layout: nodes [i, i_end) of the concatenated array
     for (;;) {
       uint32_t leaf_first = 0, leaf_count = 0;
       while (i < i_end) {
@@ -461,6 +468,7 @@ __device__ __forceinline__ int bvh_closest_hit(const DBvh B, const DScan* __rest
       if (__ballot(leaf_count != 0u) == 0ull) break;
       for (uint32_t k = 0; k < leaf_count; ++k) test_shape(B.leaf_shapes[leaf_first + k]);
     }
+    if (cached >= 0) test_shape((uint32_t)cached);
     return best;
 }
 

@@ -431,6 +431,10 @@ __global__ __launch_bounds__(RT_BLOCK, RT_WAVES_PER_EU) void k_pass(const PassPa
     float hc_r = 0.f, hc_g = 0.f, hc_b = 0.f, em_r = 0.f, em_g = 0.f, em_b = 0.f;
     float cu_r = 0.f, cu_g = 0.f, cu_b = 0.f;
     uint32_t kcount = 0, cur_brdf = 0;   // kcount: children of the current level already started
+    // FAST over a hierarchy: the children of a mirror hit all trace the same ray, so the current level remembers the answer
+    // of the first one (0 unknown, 1 no hit, shape + 2) and the other children only re-run the winner's own test
+    uint32_t c_hit = 0;
+    const bool mirror_cache = FAST && !SCENE_LDS && P.bvh.n_nodes != 0u && P.num_of_rays < 256u && P.n_shapes < 0x7FFFF0u;
     Vec3 cw = {0.f, 0.f, 0.f};           // hit.world_point
     Vec3 cv = {0.f, 0.f, 1.f};           // diffuse: hit.normal (raw); specular: the mirrored direction
     // counters (kept by the team leader)
@@ -459,12 +463,12 @@ __global__ __launch_bounds__(RT_BLOCK, RT_WAVES_PER_EU) void k_pass(const PassPa
 
     // World::ray_intersection: the linear scan of the shape table, or the hierarchy of a large scene
     auto closest_hit = [&](const Vec3 o, const Vec3 d, const float tmin, const float tmax, float& t, Vec3& lo, Vec3& ld,
-                           uint32_t& bkind) -> int {
+                           uint32_t& bkind, const int cached = -2) -> int {
         if constexpr (!SCENE_LDS) {
             if (P.bvh.n_nodes != 0u) {
                 // image renders trace with tmin 1e-5 / 1e-3 (>= 0, as the sparse form's proof needs); batch solves bring their own
                 const bool dg = AFFINE && P.scene_diag != 0u && K_MODE == 0u && __ballot(!diag_ray_ok(o, d)) == 0ull;
-                return bvh_closest_hit<AFFINE>(P.bvh, g_scan, g_wrows, P.n_shapes, o, d, tmin, tmax, t, lo, ld, bkind, dg);
+                return bvh_closest_hit<AFFINE>(P.bvh, g_scan, g_wrows, P.n_shapes, o, d, tmin, tmax, t, lo, ld, bkind, dg, cached);
             }
         }
         if constexpr (FAST && AFFINE) {
@@ -836,7 +840,9 @@ __global__ __launch_bounds__(RT_BLOCK, RT_WAVES_PER_EU) void k_pass(const PassPa
                     RT_KEEP3(lo2); RT_KEEP3(ld2);
                     asm volatile("" ::"v"(t2), "v"(b2), "v"(k2));
                 }
-                const int best = closest_hit(o, d, tmin, __builtin_inff(), t, lo, ld, bkind);
+                const bool mirror_child = mirror_cache && lvl > 0u && cur_brdf != RT_BRDF_DIFFUSE;
+                const int best = closest_hit(o, d, tmin, __builtin_inff(), t, lo, ld, bkind, mirror_child ? (int)c_hit - 2 : -2);
+                if (mirror_child) c_hit = (uint32_t)(best + 2);
                 RT_DBG_MARK(2);
                 bool leaf = true;
                 float vr, vg, vb;                                   // what the ray returns, when it is a leaf
@@ -945,12 +951,14 @@ __global__ __launch_bounds__(RT_BLOCK, RT_WAVES_PER_EU) void k_pass(const PassPa
                                     stack.st4(s, 0, make_float4(hc_r, hc_g, hc_b, em_r));
                                     stack.st4(s, 1, make_float4(em_g, em_b, cu_r, cu_g));
                                     stack.st4(s, 2, make_float4(cu_b, cw.x, cw.y, cw.z));
-                                    stack.st4(s, 3, make_float4(cv.x, cv.y, cv.z, __uint_as_float((kcount << 1) | cur_brdf)));
+                                    const uint32_t kb = mirror_cache ? (cur_brdf | (kcount << 1) | (c_hit << 9)) : ((kcount << 1) | cur_brdf);
+                                    stack.st4(s, 3, make_float4(cv.x, cv.y, cv.z, __uint_as_float(kb)));
                                 }
                                 hc_r = hc.x; hc_g = hc.y; hc_b = hc.z;
                                 em_r = em.x; em_g = em.y; em_b = em.z;
                                 cw = wp; cv = ncv;
                                 cur_brdf = nbrdf;
+                                c_hit = 0u;
                                 cu_r = 0.f; cu_g = 0.f; cu_b = 0.f;
                                 kcount = 0;
                                 lvl += 1u;
@@ -992,8 +1000,9 @@ __global__ __launch_bounds__(RT_BLOCK, RT_WAVES_PER_EU) void k_pass(const PassPa
                             cw.x = s2.y; cw.y = s2.z; cw.z = s2.w;
                             cv.x = s3.x; cv.y = s3.y; cv.z = s3.z;
                             const uint32_t kb = __float_as_uint(s3.w);
-                            kcount = kb >> 1;
+                            kcount = mirror_cache ? ((kb >> 1) & 0xFFu) : (kb >> 1);
                             cur_brdf = kb & 1u;
+                            c_hit = mirror_cache ? (kb >> 9) : 0u;
                             cu_r = cu_r + hc_r * wr; cu_g = cu_g + hc_g * wg; cu_b = cu_b + hc_b * wb;   // render.rs:168
                         }
                         RT_DBG_MARK(11);
