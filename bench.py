@@ -194,6 +194,12 @@ def main():
                     help="after the run, rank 0 compares every assembled image it still holds with a whole-frame render, bit for bit")
     args = ap.parse_args()
 
+    # stdout carries exactly one JSON line (rank 0, at the end): until then file descriptor 1 points at stderr, so that
+    # whatever native libraries print while process groups form (gloo announces its peers on stdout) cannot precede it
+    sys.stdout.flush()
+    real_stdout = os.dup(1)
+    os.dup2(2, 1)
+
     import torch
     import torch.distributed as dist
     import rustracer_amd as ra
@@ -701,7 +707,10 @@ def main():
             if outl:
                 out["outlier_fraction_vs_libm"] = outl["fraction"]
                 out["libm_comparison"] = outl
+        sys.stdout.flush()
+        os.dup2(real_stdout, 1)
         print(json.dumps(out), flush=True)
+        os.dup2(2, 1)
     if N > 1:
         images = None
         torch.cuda.synchronize()

@@ -7,6 +7,7 @@ gathered by a collective (placed by rank 0 / assembled by rt_unpack_parts).
 In every case rank 0's images must be bit-identical to a whole-frame render (--verify).  The collective variant runs
 over gloo with host staging here (two ranks cannot share one GPU under RCCL): it exercises bench.py's control flow,
 not RCCL.  Collected late on purpose: it starts child processes."""
+import json
 import os
 import socket
 import subprocess
@@ -39,7 +40,10 @@ def test_two_ranks_on_one_gpu_assemble_bit_identical_frames(scaling, gather):
         assert "pixels stored in place by every rank's kernel" in r.stderr, r.stderr[-2000:]
     if gather == "p2p":
         assert ("p2p copies in place" if scaling == "weak" else "(p2p gather)") in r.stderr, r.stderr[-2000:]
-    assert '"n_gpus": 2' in r.stdout and f'"scaling": "{scaling}"' in r.stdout
+    lines = r.stdout.strip().splitlines()
+    assert len(lines) == 1, r.stdout[:2000]      # exactly one JSON line on stdout, whatever the process groups print
+    line = json.loads(lines[0])
+    assert line["n_gpus"] == 2 and line["scaling"] == scaling
 
 
 def test_direct_stores_fall_back_to_copies_when_the_probe_fails():
