@@ -133,6 +133,8 @@ def remote_store_probe_child(argv):
     torch.cuda.set_device(device)
     fn, a = pickle.load(sys.stdin.buffer)
     images = fn(*a)                                   # (ring, h, w, 3) on rank 0's device
+    images[0].view(-1)[:1].copy_(torch.zeros(1, dtype=torch.float32, device="cuda"))   # as in the parent: a first copy
+    torch.cuda.synchronize()                          # through the mapping (it is also what turns peer access on)
     lib = _abi.lib()
     _abi.check(lib.rt_init(device))
     scene = scenes.demo_world()
