@@ -307,6 +307,9 @@ struct NodeOut {
 #ifndef RT_SCAN_GROUP
 #define RT_SCAN_GROUP 2
 #endif
+#ifndef RT_MIRROR_SIBS
+#define RT_MIRROR_SIBS 1   // siblings of a mirror hit's child resolved in the same round (throughput body, scene in LDS); measured 1 / 2 / 3 / 4 / 9: 0.641 / 0.652 / 0.657 / 0.648 / 0.742 ms per frame (none: 0.709)
+#endif
 // FAST: the throughput variant (image render, path tracer, one pass without a round budget, one lane per
 // pixel, no diagnostics): these launch parameters fold to constants, so their registers and branches go.
 #define K_ALGO (FAST ? (uint32_t)RT_ALGO_PATHTRACER : P.algorithm)
@@ -786,6 +789,11 @@ __global__ __launch_bounds__(RT_BLOCK, RT_WAVES_PER_EU) void k_pass(const PassPa
             u_rays += (uint32_t)__popcll(__ballot(busy));           // every live lane traces one ray per round
             u_diffuse += (uint32_t)__popcll(__ballot(busy && lvl > 0u && cur_brdf == RT_BRDF_DIFFUSE));
             u_specular += (uint32_t)__popcll(__ballot(busy && lvl > 0u && cur_brdf != RT_BRDF_DIFFUSE));
+            // siblings of a mirror hit's child resolved in this round, beside the child.  Scenes traced through the hierarchy
+            // keep one child per round: their mirror children rarely end as leaves (measured on the sphere-flake: 452 ms
+            // without, 510 ms with), and the remembered winner (c_hit) already spares them the traversal.
+            constexpr uint32_t kMirrorSibs = SCENE_LDS ? (uint32_t)RT_MIRROR_SIBS : 0u;
+            uint32_t sibs = 0u;
             if (busy) {
                 const uint32_t depth = lvl;                         // Ray.depth (the level-0 ray has depth 0)
                 uint64_t st = pstate;
@@ -844,18 +852,18 @@ __global__ __launch_bounds__(RT_BLOCK, RT_WAVES_PER_EU) void k_pass(const PassPa
                 const int best = closest_hit(o, d, tmin, __builtin_inff(), t, lo, ld, bkind, mirror_child ? (int)c_hit - 2 : -2);
                 if (mirror_child) c_hit = (uint32_t)(best + 2);
                 RT_DBG_MARK(2);
-                bool leaf = true;
-                float vr, vg, vb;                                   // what the ray returns, when it is a leaf
-                if (best < 0) {
-                    vr = P.bg[0]; vg = P.bg[1]; vb = P.bg[2];       // render.rs:140-143
-                } else {
+                // ---- the hit's colours before the roulette (render.rs:146-148) ----
+                Vec3 hc0 = {0.f, 0.f, 0.f}, em0 = {0.f, 0.f, 0.f};
+                uint32_t sflags = 0u;
+                float hx = 0.f, hy = 0.f, hz = 0.f, lum = 0.f;
+                const bool sphere = (bkind == RT_SHAPE_SPHERE);
+                if (best >= 0) {
                     const float4* shp = reinterpret_cast<const float4*>(shade + best);
                     const float4 sh0 = shp[0], sh1 = shp[1];
-                    Vec3 hc = {sh0.x, sh0.y, sh0.z};
-                    Vec3 em = {sh1.x, sh1.y, sh1.z};
-                    const uint32_t sflags = __float_as_uint(sh0.w);
-                    const float hx = lo.x + ld.x * t, hy = lo.y + ld.y * t, hz = lo.z + ld.z * t;   // inv_ray.at(t)
-                    const bool sphere = (bkind == RT_SHAPE_SPHERE);
+                    hc0 = {sh0.x, sh0.y, sh0.z};
+                    em0 = {sh1.x, sh1.y, sh1.z};
+                    sflags = __float_as_uint(sh0.w);
+                    hx = lo.x + ld.x * t; hy = lo.y + ld.y * t; hz = lo.z + ld.z * t;   // inv_ray.at(t)
                     if (sflags & 6u) {
                         float u, v;
                         if (sphere) {
@@ -867,147 +875,176 @@ __global__ __launch_bounds__(RT_BLOCK, RT_WAVES_PER_EU) void k_pass(const PassPa
                             v = hy - __builtin_floorf(hy);
                         }
                         const DMaterial* M = mats + (SCENE_LDS ? (uint32_t)best : scan[best].material);
-                        if (sflags & 2u) hc = pigment_color(&M->brdf_pigment, texels, u, v);
-                        if (sflags & 4u) em = pigment_color(&M->emitted, texels, u, v);
+                        if (sflags & 2u) hc0 = pigment_color(&M->brdf_pigment, texels, u, v);
+                        if (sflags & 4u) em0 = pigment_color(&M->emitted, texels, u, v);
                     }
-                    RT_DBG_MARK(6);
-                    const float lum = rt_maxf(hc.x, rt_maxf(hc.y, hc.z));
-                    bool alive = true;
-                    const bool roulette = depth >= P.rr_limit;      // render.rs:149-156
-                    float rq = 0.0f;
-                    if (roulette) {
-                        rq = rt_maxf(1.0f - lum, 0.05f);
-                        if (!(pcg_random_float(st, pinc) > rq)) {
-                            vr = em.x; vg = em.y; vb = em.z;
-                            alive = false;
+                    lum = rt_maxf(hc0.x, rt_maxf(hc0.y, hc0.z));
+                }
+                RT_DBG_MARK(6);
+                // The children of a mirror hit all trace this very ray (SpecularBRDF::scatter_ray ignores its two draws,
+                // src/material.rs:225-246), so World::ray_intersection and the pigments return for each of them what they
+                // returned just now; only the draws differ.  While this child turns out to be a leaf, up to RT_MIRROR_SIBS of
+                // the siblings that follow it are therefore resolved here as well, in order, each consuming its own draws: its
+                // two scatter draws, then the roulette and the rest exactly as below.  A sibling that opens ends the run
+                // (the recursion descends into it); rays and scatters are counted one per child as the reference does.
+                const bool mirror_level = lvl > 0u && cur_brdf != RT_BRDF_DIFFUSE;
+                for (;;) {
+                    bool leaf = true;
+                    float vr, vg, vb;                               // what the ray returns, when it is a leaf
+                    if (best < 0) {
+                        vr = P.bg[0]; vg = P.bg[1]; vb = P.bg[2];   // render.rs:140-143
+                    } else {
+                        Vec3 hc = hc0;
+                        const Vec3 em = em0;
+                        bool alive = true;
+                        const bool roulette = depth >= P.rr_limit;      // render.rs:149-156
+                        float rq = 0.0f;
+                        if (roulette) {
+                            rq = rt_maxf(1.0f - lum, 0.05f);
+                            if (!(pcg_random_float(st, pinc) > rq)) {
+                                vr = em.x; vg = em.y; vb = em.z;
+                                alive = false;
+                            }
                         }
-                    }
-                    RT_DBG_MARK(7);
-                    if (alive) {
-                        if (lum > 0.0f && n_children != 0u) {
-                            if (depth + 1u > P.max_depth) {
-                                // every child returns black without an intersection (render.rs:137-139)
-                                // but its two scatter draws are consumed (render.rs:161)
-                                st = st * P.skip_mult + pskip;
-                                // hit_color only meets zeros here: 0 + (hit_color * 1/(1-q)) * 0 is +0 for every
-                                // finite product, and 1/(1-q) <= 2^24 (q < 1 where the roulette was survived); the
-                                // survivor's divide is only paid where hit_color is not that tame
-                                const float big = 1.0e12f;
-                                const bool tame = __builtin_fabsf(hc.x) < big && __builtin_fabsf(hc.y) < big && __builtin_fabsf(hc.z) < big;
-                                float cr = 0.0f, cg = 0.0f, cb = 0.0f;
-                                if (!tame) {
+                        RT_DBG_MARK(7);
+                        if (alive) {
+                            if (lum > 0.0f && n_children != 0u) {
+                                if (depth + 1u > P.max_depth) {
+                                    // every child returns black without an intersection (render.rs:137-139)
+                                    // but its two scatter draws are consumed (render.rs:161)
+                                    st = st * P.skip_mult + pskip;
+                                    // hit_color only meets zeros here: 0 + (hit_color * 1/(1-q)) * 0 is +0 for every
+                                    // finite product, and 1/(1-q) <= 2^24 (q < 1 where the roulette was survived); the
+                                    // survivor's divide is only paid where hit_color is not that tame
+                                    const float big = 1.0e12f;
+                                    const bool tame = __builtin_fabsf(hc.x) < big && __builtin_fabsf(hc.y) < big && __builtin_fabsf(hc.z) < big;
+                                    float cr = 0.0f, cg = 0.0f, cb = 0.0f;
+                                    if (!tame) {
+                                        if (roulette) {
+                                            const float s = 1.0f / (1.0f - rq);
+                                            hc.x = hc.x * s; hc.y = hc.y * s; hc.z = hc.z * s;
+                                        }
+                                        cr = 0.0f + hc.x * 0.0f; cg = 0.0f + hc.y * 0.0f; cb = 0.0f + hc.z * 0.0f;
+                                    }
+                                    vr = em.x + cr * P.inv_num_of_rays;
+                                    vg = em.y + cg * P.inv_num_of_rays;
+                                    vb = em.z + cb * P.inv_num_of_rays;
+                                    RT_DBG_MARK(8);
+                                } else {
+                                    // the hit opens: world_point and normal (src/shape.rs:88-95, :134-138, :175-182,
+                                    // :205-209), then it becomes the current level
+                                    leaf = false;
                                     if (roulette) {
                                         const float s = 1.0f / (1.0f - rq);
                                         hc.x = hc.x * s; hc.y = hc.y * s; hc.z = hc.z * s;
                                     }
-                                    cr = 0.0f + hc.x * 0.0f; cg = 0.0f + hc.y * 0.0f; cb = 0.0f + hc.z * 0.0f;
+                                    const Rows3 MW = load_rows(mrows[best].m);
+                                    const Rows3 IW = load_rows(scan[best].inv);
+                                    const Vec3 wp = rows_point<AFFINE>(MW, AFFINE ? nullptr : g_wrows[best].m_w, hx, hy, hz);
+                                    float nx, ny, nz, dp;
+                                    if (sphere) {
+                                        dp = hx * ld.x + hy * ld.y + hz * ld.z;
+                                        nx = hx; ny = hy; nz = hz;
+                                    } else {
+                                        dp = 0.0f * ld.x + 0.0f * ld.y + 1.0f * ld.z;
+                                        nx = 0.0f; ny = 0.0f; nz = 1.0f;
+                                    }
+                                    if (!(dp < 0.0f)) { nx = -nx; ny = -ny; nz = -nz; }
+                                    const Vec3 nrm = rows_normal(IW, nx, ny, nz);
+                                    const uint32_t nbrdf = sflags & 1u;
+                                    // every child of a mirror hit has the same direction (material.rs:225-246)
+                                    const Vec3 ncv = (nbrdf == RT_BRDF_SPECULAR) ? specular_scatter_dir(d, nrm) : nrm;
+                                    if (RT_DUP_IS(3)) {
+                                        float hx2 = hx, hy2 = hy, hz2 = hz;
+                                        asm volatile("" : "+v"(hx2), "+v"(hy2), "+v"(hz2));
+                                        const Rows3 MW2 = load_rows(mrows[best].m);
+                                        const Rows3 IW2 = load_rows(scan[best].inv);
+                                        const Vec3 wp2 = rows_point<AFFINE>(MW2, AFFINE ? nullptr : g_wrows[best].m_w, hx2, hy2, hz2);
+                                        float nx2, ny2, nz2, dp2;
+                                        if (sphere) { dp2 = hx2 * ld.x + hy2 * ld.y + hz2 * ld.z; nx2 = hx2; ny2 = hy2; nz2 = hz2; }
+                                        else { dp2 = 0.0f * ld.x + 0.0f * ld.y + 1.0f * ld.z; nx2 = 0.0f; ny2 = 0.0f; nz2 = 1.0f; }
+                                        if (!(dp2 < 0.0f)) { nx2 = -nx2; ny2 = -ny2; nz2 = -nz2; }
+                                        const Vec3 nrm2 = rows_normal(IW2, nx2, ny2, nz2);
+                                        const Vec3 ncv2 = (nbrdf == RT_BRDF_SPECULAR) ? specular_scatter_dir(d, nrm2) : nrm2;
+                                        RT_KEEP3(wp2); RT_KEEP3(ncv2);
+                                    }
+                                    RT_DBG_MARK(9);
+                                    if (lvl > 0u) {
+                                        kcount += 1u;                   // this child of the level that is saved
+                                        const uint32_t s = lvl - 1u;
+                                        stack.st4(s, 0, make_float4(hc_r, hc_g, hc_b, em_r));
+                                        stack.st4(s, 1, make_float4(em_g, em_b, cu_r, cu_g));
+                                        stack.st4(s, 2, make_float4(cu_b, cw.x, cw.y, cw.z));
+                                        const uint32_t kb = mirror_cache ? (cur_brdf | (kcount << 1) | (c_hit << 9)) : ((kcount << 1) | cur_brdf);
+                                        stack.st4(s, 3, make_float4(cv.x, cv.y, cv.z, __uint_as_float(kb)));
+                                    }
+                                    hc_r = hc.x; hc_g = hc.y; hc_b = hc.z;
+                                    em_r = em.x; em_g = em.y; em_b = em.z;
+                                    cw = wp; cv = ncv;
+                                    cur_brdf = nbrdf;
+                                    c_hit = 0u;
+                                    cu_r = 0.f; cu_g = 0.f; cu_b = 0.f;
+                                    kcount = 0;
+                                    lvl += 1u;
+                                    RT_DBG_MARK(10);
                                 }
-                                vr = em.x + cr * P.inv_num_of_rays;
-                                vg = em.y + cg * P.inv_num_of_rays;
-                                vb = em.z + cb * P.inv_num_of_rays;
-                                RT_DBG_MARK(8);
                             } else {
-                                // the hit opens: world_point and normal (src/shape.rs:88-95, :134-138, :175-182,
-                                // :205-209), then it becomes the current level
-                                leaf = false;
-                                if (roulette) {
-                                    const float s = 1.0f / (1.0f - rq);
-                                    hc.x = hc.x * s; hc.y = hc.y * s; hc.z = hc.z * s;
-                                }
-                                const Rows3 MW = load_rows(mrows[best].m);
-                                const Rows3 IW = load_rows(scan[best].inv);
-                                const Vec3 wp = rows_point<AFFINE>(MW, AFFINE ? nullptr : g_wrows[best].m_w, hx, hy, hz);
-                                float nx, ny, nz, dp;
-                                if (sphere) {
-                                    dp = hx * ld.x + hy * ld.y + hz * ld.z;
-                                    nx = hx; ny = hy; nz = hz;
-                                } else {
-                                    dp = 0.0f * ld.x + 0.0f * ld.y + 1.0f * ld.z;
-                                    nx = 0.0f; ny = 0.0f; nz = 1.0f;
-                                }
-                                if (!(dp < 0.0f)) { nx = -nx; ny = -ny; nz = -nz; }
-                                const Vec3 nrm = rows_normal(IW, nx, ny, nz);
-                                const uint32_t nbrdf = sflags & 1u;
-                                // every child of a mirror hit has the same direction (material.rs:225-246)
-                                const Vec3 ncv = (nbrdf == RT_BRDF_SPECULAR) ? specular_scatter_dir(d, nrm) : nrm;
-                                if (RT_DUP_IS(3)) {
-                                    float hx2 = hx, hy2 = hy, hz2 = hz;
-                                    asm volatile("" : "+v"(hx2), "+v"(hy2), "+v"(hz2));
-                                    const Rows3 MW2 = load_rows(mrows[best].m);
-                                    const Rows3 IW2 = load_rows(scan[best].inv);
-                                    const Vec3 wp2 = rows_point<AFFINE>(MW2, AFFINE ? nullptr : g_wrows[best].m_w, hx2, hy2, hz2);
-                                    float nx2, ny2, nz2, dp2;
-                                    if (sphere) { dp2 = hx2 * ld.x + hy2 * ld.y + hz2 * ld.z; nx2 = hx2; ny2 = hy2; nz2 = hz2; }
-                                    else { dp2 = 0.0f * ld.x + 0.0f * ld.y + 1.0f * ld.z; nx2 = 0.0f; ny2 = 0.0f; nz2 = 1.0f; }
-                                    if (!(dp2 < 0.0f)) { nx2 = -nx2; ny2 = -ny2; nz2 = -nz2; }
-                                    const Vec3 nrm2 = rows_normal(IW2, nx2, ny2, nz2);
-                                    const Vec3 ncv2 = (nbrdf == RT_BRDF_SPECULAR) ? specular_scatter_dir(d, nrm2) : nrm2;
-                                    RT_KEEP3(wp2); RT_KEEP3(ncv2);
-                                }
-                                RT_DBG_MARK(9);
-                                if (lvl > 0u) {
-                                    kcount += 1u;                   // this child of the level that is saved
-                                    const uint32_t s = lvl - 1u;
-                                    stack.st4(s, 0, make_float4(hc_r, hc_g, hc_b, em_r));
-                                    stack.st4(s, 1, make_float4(em_g, em_b, cu_r, cu_g));
-                                    stack.st4(s, 2, make_float4(cu_b, cw.x, cw.y, cw.z));
-                                    const uint32_t kb = mirror_cache ? (cur_brdf | (kcount << 1) | (c_hit << 9)) : ((kcount << 1) | cur_brdf);
-                                    stack.st4(s, 3, make_float4(cv.x, cv.y, cv.z, __uint_as_float(kb)));
-                                }
-                                hc_r = hc.x; hc_g = hc.y; hc_b = hc.z;
-                                em_r = em.x; em_g = em.y; em_b = em.z;
-                                cw = wp; cv = ncv;
-                                cur_brdf = nbrdf;
-                                c_hit = 0u;
-                                cu_r = 0.f; cu_g = 0.f; cu_b = 0.f;
-                                kcount = 0;
-                                lvl += 1u;
-                                RT_DBG_MARK(10);
+                                // no children: emitted + 0 * (1/n) (render.rs:157, :171)
+                                vr = em.x + 0.0f * P.inv_num_of_rays;
+                                vg = em.y + 0.0f * P.inv_num_of_rays;
+                                vb = em.z + 0.0f * P.inv_num_of_rays;
                             }
-                        } else {
-                            // no children: emitted + 0 * (1/n) (render.rs:157, :171)
-                            vr = em.x + 0.0f * P.inv_num_of_rays;
-                            vg = em.y + 0.0f * P.inv_num_of_rays;
-                            vb = em.z + 0.0f * P.inv_num_of_rays;
                         }
                     }
-                }
-                pstate = st;
-                if (leaf) {
+                    pstate = st;
+                    if (!leaf) break;
                     if (lvl == 0u) {
                         acc_r = acc_r + vr; acc_g = acc_g + vg; acc_b = acc_b + vb;   // imagetracer.rs:119
                         busy = false;
-                    } else {
-                        cu_r = cu_r + hc_r * vr; cu_g = cu_g + hc_g * vg; cu_b = cu_b + hc_b * vb;   // render.rs:168
-                        kcount += 1u;
-                        RT_DBG_MARK(4);
-                        // levels whose children have all returned close and return to their parent
-                        while (kcount == n_children) {
-                            const float wr = em_r + cu_r * P.inv_num_of_rays;   // render.rs:171
-                            const float wg = em_g + cu_g * P.inv_num_of_rays;
-                            const float wb = em_b + cu_b * P.inv_num_of_rays;
-                            lvl -= 1u;
-                            if (lvl == 0u) {
-                                acc_r = acc_r + wr; acc_g = acc_g + wg; acc_b = acc_b + wb;   // imagetracer.rs:119
-                                busy = false;
-                                break;
-                            }
-                            const uint32_t s = lvl - 1u;
-                            const float4 s0 = stack.ld4(s, 0), s1 = stack.ld4(s, 1), s2 = stack.ld4(s, 2), s3 = stack.ld4(s, 3);
-                            hc_r = s0.x; hc_g = s0.y; hc_b = s0.z;
-                            em_r = s0.w; em_g = s1.x; em_b = s1.y;
-                            cu_r = s1.z; cu_g = s1.w; cu_b = s2.x;
-                            cw.x = s2.y; cw.y = s2.z; cw.z = s2.w;
-                            cv.x = s3.x; cv.y = s3.y; cv.z = s3.z;
-                            const uint32_t kb = __float_as_uint(s3.w);
-                            kcount = mirror_cache ? ((kb >> 1) & 0xFFu) : (kb >> 1);
-                            cur_brdf = kb & 1u;
-                            c_hit = mirror_cache ? (kb >> 9) : 0u;
-                            cu_r = cu_r + hc_r * wr; cu_g = cu_g + hc_g * wg; cu_b = cu_b + hc_b * wb;   // render.rs:168
-                        }
-                        RT_DBG_MARK(11);
+                        break;
                     }
+                    cu_r = cu_r + hc_r * vr; cu_g = cu_g + hc_g * vg; cu_b = cu_b + hc_b * vb;   // render.rs:168
+                    kcount += 1u;
+                    if (!(mirror_level && kcount < n_children && sibs < kMirrorSibs)) break;
+                    sibs += 1u;
+                    (void)pcg_random(st, pinc);                     // the sibling's scatter draws (render.rs:161)
+                    (void)pcg_random(st, pinc);
                 }
+                RT_DBG_MARK(4);
+                if (busy && lvl > 0u) {
+                    // levels whose children have all returned close and return to their parent
+                    while (kcount == n_children) {
+                        const float wr = em_r + cu_r * P.inv_num_of_rays;   // render.rs:171
+                        const float wg = em_g + cu_g * P.inv_num_of_rays;
+                        const float wb = em_b + cu_b * P.inv_num_of_rays;
+                        lvl -= 1u;
+                        if (lvl == 0u) {
+                            acc_r = acc_r + wr; acc_g = acc_g + wg; acc_b = acc_b + wb;   // imagetracer.rs:119
+                            busy = false;
+                            break;
+                        }
+                        const uint32_t s = lvl - 1u;
+                        const float4 s0 = stack.ld4(s, 0), s1 = stack.ld4(s, 1), s2 = stack.ld4(s, 2), s3 = stack.ld4(s, 3);
+                        hc_r = s0.x; hc_g = s0.y; hc_b = s0.z;
+                        em_r = s0.w; em_g = s1.x; em_b = s1.y;
+                        cu_r = s1.z; cu_g = s1.w; cu_b = s2.x;
+                        cw.x = s2.y; cw.y = s2.z; cw.z = s2.w;
+                        cv.x = s3.x; cv.y = s3.y; cv.z = s3.z;
+                        const uint32_t kb = __float_as_uint(s3.w);
+                        kcount = mirror_cache ? ((kb >> 1) & 0xFFu) : (kb >> 1);
+                        cur_brdf = kb & 1u;
+                        c_hit = mirror_cache ? (kb >> 9) : 0u;
+                        cu_r = cu_r + hc_r * wr; cu_g = cu_g + hc_g * wg; cu_b = cu_b + hc_b * wb;   // render.rs:168
+                    }
+                    RT_DBG_MARK(11);
+                }
+            }
+            // every sibling resolved above was one more ray and one more mirror scatter (counted with the whole wave active)
+#pragma unroll
+            for (uint32_t j = 0; j < kMirrorSibs; ++j) {
+                const uint32_t c = (uint32_t)__popcll(__ballot(sibs > j));
+                u_rays += c;
+                u_specular += c;
             }
             RT_DBG_MARK(5);
             continue;
