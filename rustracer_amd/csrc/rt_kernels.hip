@@ -307,8 +307,14 @@ struct NodeOut {
 #ifndef RT_SCAN_GROUP
 #define RT_SCAN_GROUP 2
 #endif
+#ifndef RT_MIRROR_RUNS
+#define RT_MIRROR_RUNS 1   // closed-form runs of a mirror hit's children whose value no draw can change (throughput body)
+#endif
 #ifndef RT_MIRROR_SIBS
-#define RT_MIRROR_SIBS 1   // siblings of a mirror hit's child resolved in the same round (throughput body, scene in LDS); measured 1 / 2 / 3 / 4 / 9: 0.641 / 0.652 / 0.657 / 0.648 / 0.742 ms per frame (none: 0.709)
+// siblings of a mirror hit's leaf child resolved in the same round through the general roulette / skip code (throughput body, scene
+// in LDS).  Measured before the closed-form run of siblings whose value no draw can change existed: 0 / 1 / 2 / 4 / 9 -> 0.709 /
+// 0.641 / 0.652 / 0.648 / 0.742 ms per frame; with it: 0 / 1 / 2 / 4 -> 0.533 / 0.547 / 0.549 / 0.553.  So: off.
+#define RT_MIRROR_SIBS 0
 #endif
 // FAST: the throughput variant (image render, path tracer, one pass without a round budget, one lane per
 // pixel, no diagnostics): these launch parameters fold to constants, so their registers and branches go.
@@ -359,6 +365,8 @@ __global__ __launch_bounds__(RT_BLOCK, RT_WAVES_PER_EU) void k_pass(const PassPa
     const uint32_t n_staged = SCENE_LDS ? P.n_shapes : 0u;
     // FAST keeps, in the slot of the team tables, the master PCG's jump by 0..63 pixels: (mult, plus) pairs
     uint64_t* lds_jump = reinterpret_cast<uint64_t*>(lds_raw);
+    uint64_t* lds_skip = lds_jump + 128;      // FAST: next to it, the pixel PCG's jump by 0..63 draws: (mult, geom) pairs
+    static_assert(sizeof(TeamTables) >= 2048, "the two jump tables live in the team tables' slot");
     DScan* lds_scan = reinterpret_cast<DScan*>(reinterpret_cast<unsigned char*>(lds_raw) + ((TEAMS || FAST) ? sizeof(TeamTables) : 0));
     DMRows* lds_mrows = reinterpret_cast<DMRows*>(lds_scan + n_staged);
     DShade* lds_shade = reinterpret_cast<DShade*>(lds_mrows + n_staged);
@@ -401,6 +409,14 @@ __global__ __launch_bounds__(RT_BLOCK, RT_WAVES_PER_EU) void k_pass(const PassPa
                 }
             lds_jump[2u * tid] = m;
             lds_jump[2u * tid + 1u] = p;
+            // the pixel PCG advanced by tid draws: s -> s * M^tid + inc * (M^(tid-1) + ... + 1)
+            uint64_t sm = 1, sg = 0;
+            for (uint32_t i = 0; i < tid; ++i) {
+                sg = sg * RT_PCG_MULT + 1ull;
+                sm = sm * RT_PCG_MULT;
+            }
+            lds_skip[2u * tid] = sm;
+            lds_skip[2u * tid + 1u] = sg;
         }
     }
     if (TEAMS || SCENE_LDS || FAST) __syncthreads();
@@ -1005,7 +1021,29 @@ __global__ __launch_bounds__(RT_BLOCK, RT_WAVES_PER_EU) void k_pass(const PassPa
                     }
                     cu_r = cu_r + hc_r * vr; cu_g = cu_g + hc_g * vg; cu_b = cu_b + hc_b * vb;   // render.rs:168
                     kcount += 1u;
-                    if (!(mirror_level && kcount < n_children && sibs < kMirrorSibs)) break;
+                    if (!(RT_MIRROR_RUNS && mirror_level && kcount < n_children)) break;
+                    {
+                        // Siblings whose value no draw can change -- the ray leaves the scene, or the hit has no children to
+                        // trace (hit_color_lum == 0) and either no roulette at this depth or an emitted colour that `+ 0`
+                        // leaves alone -- return what this child returned: all of them are folded now, in order, and the
+                        // pixel's PCG jumps over their draws (2 scatter draws each, 3 with the roulette draw).
+                        const bool roul = (best >= 0) && (depth >= P.rr_limit);
+                        const uint32_t e0 = __float_as_uint(em0.x), e1 = __float_as_uint(em0.y), e2 = __float_as_uint(em0.z);
+                        const bool plain = (e0 & 0x7FFFFFFFu) <= 0x7F800000u && e0 != 0x80000000u && (e1 & 0x7FFFFFFFu) <= 0x7F800000u &&
+                                           e1 != 0x80000000u && (e2 & 0x7FFFFFFFu) <= 0x7F800000u && e2 != 0x80000000u;
+                        const uint32_t r = n_children - kcount;
+                        const uint32_t nd = r * (roul ? 3u : 2u);
+                        if (((best < 0) || (!(lum > 0.0f) && (!roul || plain))) && nd < 64u) {
+                            st = st * lds_skip[2u * nd] + pinc * lds_skip[2u * nd + 1u];
+                            pstate = st;
+                            const float pr = hc_r * vr, pg = hc_g * vg, pb = hc_b * vb;   // render.rs:168, the same product every time
+                            for (uint32_t i = 0; i < r; ++i) { cu_r = cu_r + pr; cu_g = cu_g + pg; cu_b = cu_b + pb; }
+                            kcount = n_children;
+                            sibs += r;
+                            break;
+                        }
+                    }
+                    if (sibs >= kMirrorSibs) break;
                     sibs += 1u;
                     (void)pcg_random(st, pinc);                     // the sibling's scatter draws (render.rs:161)
                     (void)pcg_random(st, pinc);
@@ -1040,9 +1078,11 @@ __global__ __launch_bounds__(RT_BLOCK, RT_WAVES_PER_EU) void k_pass(const PassPa
                 }
             }
             // every sibling resolved above was one more ray and one more mirror scatter (counted with the whole wave active)
+            if (RT_MIRROR_RUNS && __ballot(sibs != 0u) != 0ull) {
+                uint32_t c = sibs;
 #pragma unroll
-            for (uint32_t j = 0; j < kMirrorSibs; ++j) {
-                const uint32_t c = (uint32_t)__popcll(__ballot(sibs > j));
+                for (int off = 32; off > 0; off >>= 1) c += __shfl_xor(c, off);
+                c = (uint32_t)__builtin_amdgcn_readfirstlane((int)c);
                 u_rays += c;
                 u_specular += c;
             }

@@ -273,3 +273,34 @@ def test_diagonal_inverse_specialisation_and_its_guard():
         ref2, _ = oracle(world, cam, fl, w, h, aa=2)
         g2, _ = gpu_image(world, cam, fl, w, h, aa=2)
         assert_bit_equal(g2, ref2, f"diagonal scene, flat, {type(cam).__name__}")
+
+
+@pytest.mark.parametrize("n,d,rr_limit", [(4, 3, 0), (10, 2, 1), (3, 4, 2), (10, 3, 3), (70, 1, 0)])
+def test_mirror_children_runs_and_their_exactness_conditions(n, d, rr_limit, monkeypatch):
+    """The children of a mirror hit trace one ray; where no draw can change their value the throughput body folds the rest
+    of them at once and jumps the pixel's PCG over their draws (k_pass FAST, `RT_MIRROR_RUNS`).  That is only exact if
+    `emitted + 0` leaves the emitted colour alone, so emitted colours of -0, NaN and inf -- with and without a roulette
+    draw at that depth -- must take the one-by-one path; rays that leave the scene return a background with a -0 in it;
+    70 children exceed the jump table (3 * 69 draws) and fall back too."""
+    monkeypatch.setenv("RUSTRACER_MAX_TEAM", "1")            # small frames through the throughput body
+    w, h = 80, 56
+    mirror = ra.Material(ra.SpecularBRDF(ra.UniformPigment((0.7, 0.6, 0.9))), ra.UniformPigment(ra.BLACK))
+    grey = ra.Material(ra.DiffuseBRDF(ra.UniformPigment((0.5, 0.5, 0.5))), ra.UniformPigment(ra.BLACK))
+    for emitted, with_sky, bg in [((1.0, 0.9, 0.5), True, ra.BLACK), ((-0.0, 0.5, 1.0), True, ra.BLACK),
+                                  ((float("nan"), 0.2, -0.0), True, ra.BLACK), ((float("inf"), 0.0, 0.3), True, ra.BLACK),
+                                  (None, False, (0.1, -0.0, 0.3))]:
+        world = ra.World()
+        if with_sky:
+            world.add(ra.Sphere(ra.scaling((40.0, 40.0, 40.0)),
+                                ra.Material(ra.DiffuseBRDF(ra.UniformPigment(ra.BLACK)), ra.UniformPigment(emitted))))
+        world.add(ra.Plane(ra.translation((0.0, 0.0, -1.0)), grey))
+        world.add(ra.Sphere(ra.translation((0.3, -0.4, 0.0)), mirror))
+        world.add(ra.Sphere(ra.translation((0.8, 1.4, -0.4)) * ra.scaling((0.6, 0.6, 0.6)), mirror))
+        cam = ra.PerspectiveCamera(1.0, w / h, ra.translation((-2.5, 0.0, 0.3)))
+        rr = ra.PathTracer(world, bg, n, d, rr_limit)
+        ref, rs = oracle(world, cam, rr, w, h)
+        for schedule in [(0,), ()]:
+            g, gs = gpu_render(world, cam, rr, w, h, schedule=schedule)
+            assert_bit_equal(g.cpu().numpy(), ref, f"mirror runs, emitted={emitted}, bg={bg}, schedule={schedule}")
+            for k in COUNTERS:
+                assert gs[k] == rs[k], (emitted, schedule, k, gs[k], rs[k])
