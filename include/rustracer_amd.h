@@ -132,6 +132,9 @@ typedef struct rt_stats {
     uint64_t diffuse_scatters, specular_scatters; /* BRDF::scatter_ray calls whose ray is traced */
     double kernel_ms;     /* device time of the render kernels of this call (HIP events) */
     double total_ms;      /* host wall time of the call */
+    uint64_t rays_shared; /* of `rays`: children of a mirror hit that took the answer of the sibling traced before them
+                             (the same ray, src/material.rs:225-246) without running the shape tests again; counted in
+                             `rays`, `sphere_tests` and `plane_tests` as the reference counts them */
 } rt_stats;
 
 typedef struct rt_scene rt_scene; /* device-resident World + textures (opaque) */
@@ -254,7 +257,7 @@ int rt_brdf_scatter_ray(uint32_t brdf, const float* rf, const float* incoming_di
 
 /* Evaluate include/rt_strict_math.h on the GPU (fn: 0 sin, 1 cos, 2 atan2(y=a,x=b), 3 acos,
  * 4 a/b, 5 sqrt(a) as the render kernels compute it, 6 its short form for a == 0 or a >= 2^-96,
- * 7 rt_maxf(a, b), 8 the bits of rt_f32_to_u32_sat(a));
+ * 7 rt_maxf of a and b, 8 the bits of rt_f32_to_u32_sat of a);
  * used to prove host/device bit-equality of the shared math. */
 int rt_strict_math_eval(int fn, const float* a, const float* b, uint64_t n, float* out);
 

@@ -610,6 +610,7 @@ int oracle_fire_all_rays(const rt_shape* shapes, uint32_t n_shapes, const rt_mat
         stats->rays = tot.rays; stats->samples = tot.samples;
         stats->sphere_tests = tot.sphere_tests; stats->plane_tests = tot.plane_tests;
         stats->diffuse_scatters = tot.diffuse_scatters; stats->specular_scatters = tot.specular_scatters;
+        stats->rays_shared = 0;                          // the reference traces every child
         stats->kernel_ms = std::chrono::duration<double, std::milli>(t2 - t1).count();  // par_iter part
         stats->total_ms = std::chrono::duration<double, std::milli>(t2 - t0).count();   // incl. all_rays
     }

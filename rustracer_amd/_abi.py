@@ -71,7 +71,7 @@ class rt_stats(C.Structure):
     _fields_ = [("rays", C.c_uint64), ("samples", C.c_uint64),
                 ("sphere_tests", C.c_uint64), ("plane_tests", C.c_uint64),
                 ("diffuse_scatters", C.c_uint64), ("specular_scatters", C.c_uint64),
-                ("kernel_ms", C.c_double), ("total_ms", C.c_double)]
+                ("kernel_ms", C.c_double), ("total_ms", C.c_double), ("rays_shared", C.c_uint64)]
 
     def as_dict(self):
         return {n: getattr(self, n) for n, _ in self._fields_}

@@ -52,8 +52,8 @@ namespace rtd {
 struct PassCtl {
     uint32_t head[RT_MAX_PASSES];        // consumption head of pass p's input
     uint32_t count[RT_MAX_PASSES + 1];   // entries parked for pass p
-    uint32_t pad[7];
-    unsigned long long counters[4];      // [0] rays [1] samples [2] diffuse [3] specular
+    uint32_t pad[5];
+    unsigned long long counters[5];      // [0] rays [1] samples [2] diffuse [3] specular [4] rays answered from a sibling's query
 };
 static_assert(sizeof(PassCtl) == 256, "PassCtl layout");
 
@@ -458,7 +458,7 @@ __global__ __launch_bounds__(RT_BLOCK, RT_WAVES_PER_EU) void k_pass(const PassPa
     Vec3 cv = {0.f, 0.f, 1.f};           // diffuse: hit.normal (raw); specular: the mirrored direction
     // counters (kept by the team leader)
     uint32_t n_rays = 0, n_samples = 0, n_diffuse = 0, n_specular = 0;
-    uint32_t u_rays = 0, u_samples = 0, u_diffuse = 0, u_specular = 0;   // FAST: the same, wave-uniform (ballot counts)
+    uint32_t u_rays = 0, u_samples = 0, u_diffuse = 0, u_specular = 0, u_shared = 0;   // FAST: the same, wave-uniform (ballot counts)
 
     // wave-private slice of the input queue
     uint32_t wcur = 0, wend = 0;
@@ -1085,6 +1085,7 @@ __global__ __launch_bounds__(RT_BLOCK, RT_WAVES_PER_EU) void k_pass(const PassPa
                 c = (uint32_t)__builtin_amdgcn_readfirstlane((int)c);
                 u_rays += c;
                 u_specular += c;
+                u_shared += c;
             }
             RT_DBG_MARK(5);
             continue;
@@ -1352,6 +1353,7 @@ __global__ __launch_bounds__(RT_BLOCK, RT_WAVES_PER_EU) void k_pass(const PassPa
                 if (u_samples) atomicAdd(&P.ctl->counters[1], (unsigned long long)u_samples);
                 if (u_diffuse) atomicAdd(&P.ctl->counters[2], (unsigned long long)u_diffuse);
                 if (u_specular) atomicAdd(&P.ctl->counters[3], (unsigned long long)u_specular);
+                if (u_shared) atomicAdd(&P.ctl->counters[4], (unsigned long long)u_shared);
             }
         } else {
             flush(n_rays, 0); flush(n_samples, 1); flush(n_diffuse, 2); flush(n_specular, 3);

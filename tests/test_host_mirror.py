@@ -193,7 +193,7 @@ def test_flatten_demo_world_preserves_order_and_dedups_materials():
 def test_abi_struct_sizes_match_header():
     sizes = {_abi.rt_shape: 136, _abi.rt_pigment: 36, _abi.rt_material: 76, _abi.rt_texture: 16, _abi.rt_camera: 76,
              _abi.rt_renderer: 40, _abi.rt_ray: 36, _abi.rt_hit: 44, _abi.rt_pcg: 16, _abi.rt_partition: 20,
-             _abi.rt_stats: 64}
+             _abi.rt_stats: 72}
     for t, n in sizes.items():
         assert C.sizeof(t) == n, t
 
