@@ -310,6 +310,20 @@ struct NodeOut {
 #ifndef RT_MIRROR_RUNS
 #define RT_MIRROR_RUNS 1   // closed-form runs of a mirror hit's children whose value no draw can change (throughput body)
 #endif
+#ifndef RT_DRAIN_HELPERS
+// Throughput body, queue dry: lanes without a pixel trace later siblings of another lane's last-level hit under hypotheses about
+// the draws the earlier siblings consume (see "drain helpers" in the round loop).  0 compiles it out.
+#define RT_DRAIN_HELPERS 1
+#endif
+#ifndef RT_HELP_MIN
+#define RT_HELP_MIN 2      // free lanes per speculating lane from which a wave speculates (1 / 2 / 3: 2.26 / 2.24 / 2.37 ms for a 1080p frame)
+#endif
+#ifndef RT_CHUNK
+#define RT_CHUNK 64        // throughput body: pixels per queue hand-out (a divisor of 64)
+#endif
+#ifndef RT_MIRROR_DRAIN
+#define RT_MIRROR_DRAIN 1  // throughput body, queue dry: all siblings of a mirror hit's leaf child in one round (2: hierarchy scenes too)
+#endif
 #ifndef RT_MIRROR_SIBS
 // siblings of a mirror hit's leaf child resolved in the same round through the general roulette / skip code (throughput body, scene
 // in LDS).  Measured before the closed-form run of siblings whose value no draw can change existed: 0 / 1 / 2 / 4 / 9 -> 0.709 /
@@ -327,7 +341,7 @@ struct NodeOut {
 #else
 #define K_DEBUG (FAST ? (unsigned long long*)nullptr : P.debug_waves)
 #endif
-template <bool AFFINE, bool STACK_LDS, bool SCENE_LDS, bool TEAMS, bool FAST>
+template <bool AFFINE, bool STACK_LDS, bool SCENE_LDS, bool TEAMS, int FAST>
 __global__ __launch_bounds__(RT_BLOCK, RT_WAVES_PER_EU) void k_pass(const PassParams P, const DScan* __restrict__ g_scan,
                                                    const DMRows* __restrict__ g_mrows,
                                                    const DWRows* __restrict__ g_wrows,
@@ -335,6 +349,8 @@ __global__ __launch_bounds__(RT_BLOCK, RT_WAVES_PER_EU) void k_pass(const PassPa
                                                    const DMaterial* __restrict__ g_materials,
                                                    const float* __restrict__ texels) {
     extern __shared__ float4 lds_raw[];
+    // FAST == 2: the throughput body with drain helpers, for launches short enough that their end matters (a frame or a few)
+    constexpr bool HELP = (FAST == 2) && (RT_DRAIN_HELPERS != 0);
     const uint32_t tid = threadIdx.x;
     const uint32_t lane = tid & 63u;
     const uint32_t gtid = blockIdx.x * RT_BLOCK + tid;
@@ -366,7 +382,11 @@ __global__ __launch_bounds__(RT_BLOCK, RT_WAVES_PER_EU) void k_pass(const PassPa
     // FAST keeps, in the slot of the team tables, the master PCG's jump by 0..63 pixels: (mult, plus) pairs
     uint64_t* lds_jump = reinterpret_cast<uint64_t*>(lds_raw);
     uint64_t* lds_skip = lds_jump + 128;      // FAST: next to it, the pixel PCG's jump by 0..63 draws: (mult, geom) pairs
-    static_assert(sizeof(TeamTables) >= 2048, "the two jump tables live in the team tables' slot");
+    uint64_t* lds_sv = lds_jump + 256;        // FAST: the pixel PCG's jump by s * 2 * num_of_rays draws, s = 0..15: (mult, geom) pairs
+    uint8_t* lds_tri = reinterpret_cast<uint8_t*>(lds_jump + 288);   // FAST: candidate slot c -> sibling j (c = j (j + 1) / 2 + s, s <= j)
+    // FAST: per wave, the lanes that speculate [0..63] and the free lanes [64..127], each by rank
+    volatile uint8_t* lds_wv = lds_tri + 64u + (tid >> 6) * 128u;
+    static_assert(sizeof(TeamTables) >= 2048 + 256 + 64 + (RT_BLOCK / 64) * 128, "the FAST tables live in the team tables' slot");
     DScan* lds_scan = reinterpret_cast<DScan*>(reinterpret_cast<unsigned char*>(lds_raw) + ((TEAMS || FAST) ? sizeof(TeamTables) : 0));
     DMRows* lds_mrows = reinterpret_cast<DMRows*>(lds_scan + n_staged);
     DShade* lds_shade = reinterpret_cast<DShade*>(lds_mrows + n_staged);
@@ -417,6 +437,19 @@ __global__ __launch_bounds__(RT_BLOCK, RT_WAVES_PER_EU) void k_pass(const PassPa
             }
             lds_skip[2u * tid] = sm;
             lds_skip[2u * tid + 1u] = sg;
+            if (tid < 16u) {
+                // tid skips of 2 * num_of_rays draws composed: s -> s * vm + inc * vg
+                uint64_t vm = 1, vg = 0;
+                for (uint32_t i = 0; i < tid; ++i) {
+                    vg = vg * P.skip_mult + P.skip_plus;
+                    vm = vm * P.skip_mult;
+                }
+                lds_sv[2u * tid] = vm;
+                lds_sv[2u * tid + 1u] = vg;
+            }
+            uint32_t tj = 0;
+            while ((tj + 1u) * (tj + 2u) / 2u <= tid) ++tj;
+            lds_tri[tid] = (uint8_t)tj;
         }
     }
     if (TEAMS || SCENE_LDS || FAST) __syncthreads();
@@ -468,6 +501,9 @@ __global__ __launch_bounds__(RT_BLOCK, RT_WAVES_PER_EU) void k_pass(const PassPa
     // diagnostics
     unsigned long long dbg_t0 = 0;
     uint32_t dbg_rounds = 0, dbg_lanes = 0;
+#ifdef RT_HELP_DEBUG
+    uint32_t hd_ex = 0, hd_few = 0, hd_eng = 0, hd_own = 0;
+#endif
     if (K_DEBUG) dbg_t0 = __builtin_amdgcn_s_memrealtime();
     // section cycle counters (diagnostics): 0 generate 1 scatter 2 scan 3 hit+shade 4 resolve 5 park
     uint32_t dbg_sec0 = 0, dbg_sec1 = 0, dbg_sec2 = 0, dbg_sec3 = 0, dbg_sec4 = 0, dbg_sec5 = 0;
@@ -668,11 +704,14 @@ __global__ __launch_bounds__(RT_BLOCK, RT_WAVES_PER_EU) void k_pass(const PassPa
             while (wantmask != 0ull) {
                 if (wcur == wend) {
                     uint32_t b = 0;
-                    if (lane == 0) b = atomicAdd(&P.ctl->head[K_PASS], n_teams);
+                    // FAST hands out RT_CHUNK pixels at a time: a wave's lanes then hold pixels of several image regions, so the
+                    // long pixels of one region do not all end up in the same wave
+                    const uint32_t chunk = FAST ? (uint32_t)RT_CHUNK : n_teams;
+                    if (lane == 0) b = atomicAdd(&P.ctl->head[K_PASS], chunk);
                     b = __shfl(b, 0);
                     if (b >= n_in) { exhausted = true; break; }
                     wcur = b;
-                    wend = (b + n_teams < n_in) ? b + n_teams : n_in;
+                    wend = (b + chunk < n_in) ? b + chunk : n_in;
                     if (K_PASS == 0u && K_MODE == 0u) {
                         // master PCG at the chunk's first pixel, on the scalar unit (imagetracer.rs:63-81)
                         wbase_h = b;
@@ -808,9 +847,84 @@ __global__ __launch_bounds__(RT_BLOCK, RT_WAVES_PER_EU) void k_pass(const PassPa
             // siblings of a mirror hit's child resolved in this round, beside the child.  Scenes traced through the hierarchy
             // keep one child per round: their mirror children rarely end as leaves (measured on the sphere-flake: 452 ms
             // without, 510 ms with), and the remembered winner (c_hit) already spares them the traversal.
-            constexpr uint32_t kMirrorSibs = SCENE_LDS ? (uint32_t)RT_MIRROR_SIBS : 0u;
+            // Once the queue is dry (the wave's lanes only drain), every remaining sibling is resolved in the same round: the long
+            // chains of a frame are mirror chains (ten identical rays per mirror hit, each survivor of the roulette skipping twenty
+            // draws), and a sibling costs a few dozen instructions against a round's several hundred.
+            const uint32_t kMirrorSibs = (RT_MIRROR_DRAIN && exhausted && (SCENE_LDS || RT_MIRROR_DRAIN > 1)) ? n_children
+                                         : (SCENE_LDS ? (uint32_t)RT_MIRROR_SIBS : 0u);
             uint32_t sibs = 0u;
-            if (busy) {
+            // ---- drain helpers ------------------------------------------------------------------------------------------
+            // Once the queue is dry a wave's lanes fall idle one by one while the pixels left run chains of up to
+            // 1 + n + n^2 + ... sequential rays.  Nine in ten of those rays are children of a last-level hit: such a child cannot
+            // open, so after its two scatter draws it consumes `pred` draws (the roulette draw, if any) or pred + 2 n (a survivor's
+            // children draw without tracing, render.rs:137-139, :161).  The PCG state at sibling j is therefore known up to the
+            // number s of survivors before it.  Free lanes (no pixel, nothing pending) take a copy of a speculating lane's
+            // hit and trace (sibling j, s survivors) pairs, slot c = j (j + 1) / 2 + s, at the state jumped by j (2 + pred) + 2 n s
+            // draws; afterwards the owner walks the siblings in order along the pairs that came true and folds their radiances in
+            // sibling order, adopting the PCG state of the last one.  Every draw and every f32 operation is the sequential
+            // recursion's; a pair that did not come true is discarded (and never counted as a ray).
+            uint32_t hT = 0u;                 // candidates per speculating lane this round, its own included (wave-uniform)
+            bool helper = false, spec_own = false;
+            uint32_t h_rank = 0u;             // rank of the speculating lane (its own, or the one this helper works for)
+            uint32_t sv_c = 3u;               // outcome of this lane's candidate: 0 consumed pred, 1 pred + 2n, 2 off the grid, 3 none
+            float sv_r = 0.f, sv_g = 0.f, sv_b = 0.f;
+            const uint32_t h_pred = (P.max_depth >= P.rr_limit) ? 1u : 0u;
+            if (HELP && exhausted && P.max_depth != 0u) {
+                const bool own = busy && lvl == P.max_depth && cur_brdf == RT_BRDF_DIFFUSE && kcount + 2u <= n_children;
+                const bool freel = !busy && q == RT_INVALID;
+                const unsigned long long m_own = __ballot(own), m_free = __ballot(freel);
+                const uint32_t n_own = (uint32_t)__popcll(m_own), n_free = (uint32_t)__popcll(m_free);
+                if (n_own != 0u && n_free >= (uint32_t)RT_HELP_MIN * n_own) {
+                    uint32_t hh = n_free / n_own;
+                    if (hh > 54u) hh = 54u;
+                    hT = hh + 1u;
+                    const uint32_t r_own = __builtin_amdgcn_mbcnt_hi((uint32_t)(m_own >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m_own, 0u));
+                    const uint32_t r_free = __builtin_amdgcn_mbcnt_hi((uint32_t)(m_free >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m_free, 0u));
+                    if (own) lds_wv[r_own] = (uint8_t)lane;
+                    if (freel) lds_wv[64u + r_free] = (uint8_t)lane;
+                    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+                    __builtin_amdgcn_wave_barrier();
+                    spec_own = own;
+                    h_rank = r_own;
+                    uint32_t h_slot = 0u;
+                    if (freel && r_free < n_own * hh) {
+                        const float inv_hh = 1.0f / (float)hh;
+                        const uint32_t oi = (uint32_t)(((float)r_free + 0.5f) * inv_hh);   // r_free / hh (both below 64)
+                        h_slot = 1u + r_free - oi * hh;
+                        h_rank = oi;
+                        helper = true;
+                    }
+                    // a helper takes a copy of its lane's open hit (every lane runs the shuffles; the others read themselves)
+                    const uint32_t src = helper ? (uint32_t)lds_wv[h_rank] : lane;
+                    const uint64_t g_state = shfl_u64(pstate, src), g_inc = shfl_u64(pinc, src);
+                    const float g0 = __shfl(cw.x, src), g1 = __shfl(cw.y, src), g2 = __shfl(cw.z, src);
+                    const float g3 = __shfl(cv.x, src), g4 = __shfl(cv.y, src), g5 = __shfl(cv.z, src);
+                    const uint32_t g_k = __shfl(kcount, src);
+                    if (helper) {
+                        const uint32_t cj = lds_tri[h_slot], cs = h_slot - cj * (cj + 1u) / 2u;
+                        const uint32_t jd = cj * (2u + h_pred);
+                        if (cj < n_children - g_k && jd < 64u && cs < 16u) {
+                            pinc = g_inc;
+                            pskip = g_inc * P.skip_plus;
+                            uint64_t js = g_state * lds_skip[2u * jd] + g_inc * lds_skip[2u * jd + 1u];
+                            js = js * lds_sv[2u * cs] + g_inc * lds_sv[2u * cs + 1u];
+                            pstate = js;
+                            cw = {g0, g1, g2};
+                            cv = {g3, g4, g5};
+                            cur_brdf = RT_BRDF_DIFFUSE;
+                            lvl = P.max_depth;
+                        } else {
+                            helper = false;       // the pair does not exist for this hit (or lies beyond the jump tables)
+                        }
+                    }
+                }
+            }
+            const bool spec = helper || spec_own;
+#ifdef RT_HELP_DEBUG
+            if (exhausted) { hd_ex += 1u; if (__popcll(__ballot(busy)) <= 16) hd_few += 1u; if (__ballot(busy && lvl == P.max_depth && cur_brdf == RT_BRDF_DIFFUSE) != 0ull) hd_own += 1u; }
+            if (hT != 0u) hd_eng += 1u;
+#endif
+            if (busy || helper) {
                 const uint32_t depth = lvl;                         // Ray.depth (the level-0 ray has depth 0)
                 uint64_t st = pstate;
                 Vec3 o, d;
@@ -906,6 +1020,7 @@ __global__ __launch_bounds__(RT_BLOCK, RT_WAVES_PER_EU) void k_pass(const PassPa
                 const bool mirror_level = lvl > 0u && cur_brdf != RT_BRDF_DIFFUSE;
                 for (;;) {
                     bool leaf = true;
+                    bool skipped = false;                           // a survivor at the last level: its children's draws were skipped
                     float vr, vg, vb;                               // what the ray returns, when it is a leaf
                     if (best < 0) {
                         vr = P.bg[0]; vg = P.bg[1]; vb = P.bg[2];   // render.rs:140-143
@@ -929,6 +1044,7 @@ __global__ __launch_bounds__(RT_BLOCK, RT_WAVES_PER_EU) void k_pass(const PassPa
                                     // every child returns black without an intersection (render.rs:137-139)
                                     // but its two scatter draws are consumed (render.rs:161)
                                     st = st * P.skip_mult + pskip;
+                                    skipped = true;
                                     // hit_color only meets zeros here: 0 + (hit_color * 1/(1-q)) * 0 is +0 for every
                                     // finite product, and 1/(1-q) <= 2^24 (q < 1 where the roulette was survived); the
                                     // survivor's divide is only paid where hit_color is not that tame
@@ -1019,6 +1135,12 @@ __global__ __launch_bounds__(RT_BLOCK, RT_WAVES_PER_EU) void k_pass(const PassPa
                         busy = false;
                         break;
                     }
+                    if (HELP && spec) {
+                        // a candidate of the drain helpers (always a leaf: it was traced at the last level): the walk below folds it
+                        sv_r = vr; sv_g = vg; sv_b = vb;
+                        sv_c = (best < 0) ? (h_pred != 0u ? 2u : 0u) : (skipped ? 1u : 0u);
+                        break;
+                    }
                     cu_r = cu_r + hc_r * vr; cu_g = cu_g + hc_g * vg; cu_b = cu_b + hc_b * vb;   // render.rs:168
                     kcount += 1u;
                     if (!(RT_MIRROR_RUNS && mirror_level && kcount < n_children)) break;
@@ -1049,6 +1171,49 @@ __global__ __launch_bounds__(RT_BLOCK, RT_WAVES_PER_EU) void k_pass(const PassPa
                     (void)pcg_random(st, pinc);
                 }
                 RT_DBG_MARK(4);
+            }
+            if (HELP && hT != 0u) {
+                // the walk (every lane runs the shuffles: a lane that is switched off cannot be read)
+                uint32_t wj = 0u, wsv = 0u, extra = 0u;
+                bool walking = spec_own;
+                const uint32_t hbase = 64u + h_rank * (hT - 1u) - 1u;
+                for (;;) {
+                    uint32_t src = lane;
+                    if (walking && wj != 0u) {
+                        const uint32_t c = wj * (wj + 1u) / 2u + wsv;
+                        if (c < hT) src = (uint32_t)lds_wv[hbase + c];
+                        else walking = false;                       // nobody traced this pair
+                    }
+                    if (__ballot(walking) == 0ull) break;
+                    const float gr = __shfl(sv_r, src), gg = __shfl(sv_g, src), gb = __shfl(sv_b, src);
+                    const uint32_t gc = __shfl(sv_c, src);
+                    const uint64_t gs = shfl_u64(pstate, src);
+                    if (walking) {
+                        if (gc == 3u) {
+                            walking = false;                        // the pair was not traced
+                        } else {
+                            cu_r = cu_r + hc_r * gr; cu_g = cu_g + hc_g * gg; cu_b = cu_b + hc_b * gb;   // render.rs:168
+                            kcount += 1u;
+                            pstate = gs;
+                            if (wj != 0u) extra += 1u;
+                            if (gc == 1u) wsv += 1u;
+                            else if (gc == 2u) walking = false;     // a ray that left the scene drew nothing: off the grid
+                            wj += 1u;
+                            if (kcount == n_children) walking = false;
+                        }
+                    }
+                }
+                // the siblings taken from helpers are rays and diffuse scatters of the reference like any other
+#pragma unroll
+                for (int off = 32; off > 0; off >>= 1) extra += __shfl_xor(extra, off);
+                extra = (uint32_t)__builtin_amdgcn_readfirstlane((int)extra);
+                u_rays += extra;
+                u_diffuse += extra;
+#ifdef RT_HELP_DEBUG
+                u_shared += extra;
+#endif
+            }
+            {
                 if (busy && lvl > 0u) {
                     // levels whose children have all returned close and return to their parent
                     while (kcount == n_children) {
@@ -1339,6 +1504,9 @@ __global__ __launch_bounds__(RT_BLOCK, RT_WAVES_PER_EU) void k_pass(const PassPa
         d[0] = dbg_t0; d[1] = __builtin_amdgcn_s_memrealtime(); d[2] = dbg_rounds; d[3] = dbg_lanes; d[4] = T;
         d[5] = dbg_sec0; d[6] = dbg_sec1; d[7] = dbg_sec2; d[8] = dbg_sec3; d[9] = dbg_sec4; d[10] = dbg_sec5;
         d[11] = dbg_sec6; d[12] = dbg_sec7; d[13] = dbg_sec8; d[14] = dbg_sec9; d[15] = dbg_sec10; d[16] = dbg_sec11;
+#ifdef RT_HELP_DEBUG
+        d[13] = hd_ex; d[14] = hd_few; d[15] = hd_eng; d[16] = hd_own;
+#endif
     }
     // ---- counters: wave reduction, one atomic per wave and counter ----
     {

@@ -304,3 +304,35 @@ def test_mirror_children_runs_and_their_exactness_conditions(n, d, rr_limit, mon
             assert_bit_equal(g.cpu().numpy(), ref, f"mirror runs, emitted={emitted}, bg={bg}, schedule={schedule}")
             for k in COUNTERS:
                 assert gs[k] == rs[k], (emitted, schedule, k, gs[k], rs[k])
+
+
+@pytest.mark.parametrize("n,d,rr_limit", [(10, 3, 3), (10, 3, 5), (10, 2, 0), (3, 3, 1), (30, 2, 2), (2, 4, 2), (1, 3, 0)])
+@pytest.mark.parametrize("helpers", ["0", "1000000"])
+def test_drain_helpers_and_same_round_mirror_siblings_are_exact(n, d, rr_limit, helpers, monkeypatch):
+    """Once the queue is dry the throughput body (k_pass FAST) (a) resolves all remaining siblings of a mirror hit's leaf child
+    in one round and (b), in launches of few pixels per lane, lets free lanes trace later siblings of another lane's
+    last-level diffuse hit at speculated PCG offsets (FAST == 2, `RUSTRACER_HELP_PIXELS_PER_LANE`).  Both must reproduce the
+    sequential recursion bit for bit: with a roulette draw at the last level (rr_limit <= max_depth) and without, with
+    rays that leave the scene (no sky: they draw nothing, which takes a sibling off the speculated grid), with more
+    children than the jump tables cover (n = 30), a single child (nothing to speculate) and every counter equal."""
+    monkeypatch.setenv("RUSTRACER_MAX_TEAM", "1")            # small frames through the throughput body
+    monkeypatch.setenv("RUSTRACER_HELP_PIXELS_PER_LANE", helpers)
+    w, h = 96, 64
+    mirror = ra.Material(ra.SpecularBRDF(ra.UniformPigment((0.7, 0.6, 0.9))), ra.UniformPigment(ra.BLACK))
+    grey = ra.Material(ra.DiffuseBRDF(ra.CheckeredPigment((0.5, 0.5, 0.5), (0.9, 0.2, 0.1), 6)), ra.UniformPigment(ra.BLACK))
+    blue = ra.Material(ra.DiffuseBRDF(ra.UniformPigment((0.3, 0.4, 0.8))), ra.UniformPigment((0.05, 0.0, 0.1)))
+    for with_sky, bg in [(True, ra.BLACK), (False, (0.2, 0.3, 0.9))]:
+        world = ra.World()
+        if with_sky:
+            world.add(ra.Sphere(ra.scaling((40.0, 40.0, 40.0)),
+                                ra.Material(ra.DiffuseBRDF(ra.UniformPigment(ra.BLACK)), ra.UniformPigment((1.0, 0.9, 0.5)))))
+        world.add(ra.Plane(ra.translation((0.0, 0.0, -1.0)), grey))
+        world.add(ra.Sphere(ra.translation((0.3, -0.6, -0.2)), blue))
+        world.add(ra.Sphere(ra.translation((0.8, 1.4, -0.4)) * ra.scaling((0.6, 0.6, 0.6)), mirror))
+        cam = ra.PerspectiveCamera(1.0, w / h, ra.translation((-2.5, 0.0, 0.3)))
+        rr = ra.PathTracer(world, bg, n, d, rr_limit)
+        ref, rs = oracle(world, cam, rr, w, h)
+        g, gs = gpu_render(world, cam, rr, w, h, schedule=(0,))
+        assert_bit_equal(g.cpu().numpy(), ref, f"drain helpers={helpers}, sky={with_sky}, n={n} d={d} rr={rr_limit}")
+        for k in COUNTERS:
+            assert gs[k] == rs[k], (with_sky, k, gs[k], rs[k])

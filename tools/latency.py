@@ -16,7 +16,7 @@ for name, sched in (("short passes + teams", ()), ("one pass (FAST)", (0,))):
         st = _abi.rt_stats()
         _abi.check(lib.rt_render(dev.handle, C.byref(cam), C.byref(rr), W, H, 42, 54, 1, None, img.data_ptr(), None, C.byref(st)))
         best = min(best, st.kernel_ms)
-    print(f"{name:24s} kernel {best:.3f} ms  rays {st.rays}")
+    print(f"{name:24s} kernel {best:.3f} ms  rays {st.rays} shared {st.rays_shared}")
 # the literal drop-in call: host buffers in, host image out (scene upload, render, 24.9 MB D2H)
 import time
 import numpy as np

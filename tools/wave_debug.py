@@ -43,3 +43,8 @@ for p in range(n_pass):
           f"| wave-rounds {rounds.sum():.3e} lanes/round {lanes.sum()/max(rounds.sum(),1):.1f} | us/round {(life.sum()/max(rounds.sum(),1)):.2f}")
     print("        cycles/round: generate %.0f scatter %.0f scan %.0f shade-rest %.0f fold %.0f park/rest %.0f | hit+pigment %.0f roulette %.0f leaf/skip %.0f open %.0f push %.0f pop %.0f  (total %.0f)" % (tuple(sec) + (sec.sum(),)))
 print(f"total wave-rounds {tot_rounds:.3e}")
+if os.environ.get("HELP_DEBUG"):
+    o = np.argsort(-d[0, :, 2])[:12]
+    for w in o:
+        r = d[0, w]
+        print(f"wave {w}: rounds {int(r[2])} lanes/round {r[3]/max(r[2],1):.1f} life {(r[1]-r[0])/100:.0f} us | exhausted rounds {int(r[13])} of which <=16 live {int(r[14])}, with a last-level diffuse lane {int(r[16])}, engaged {int(r[15])}")
