@@ -318,6 +318,9 @@ struct NodeOut {
 #ifndef RT_HELP_MIN
 #define RT_HELP_MIN 2      // free lanes per speculating lane from which a wave speculates (1 / 2 / 3: 2.26 / 2.24 / 2.37 ms for a 1080p frame)
 #endif
+#ifndef RT_SUBCHUNKS
+#define RT_SUBCHUNKS 4     // FAST == 2: runs of consecutive pixels per 64-entry hand-out (1 / 4 / 8 / 16: 2.33 / 2.07 / 2.11 / 2.02 ms for a 1080p frame)
+#endif
 #ifndef RT_CHUNK
 #define RT_CHUNK 64        // throughput body: pixels per queue hand-out (a divisor of 64)
 #endif
@@ -497,6 +500,11 @@ __global__ __launch_bounds__(RT_BLOCK, RT_WAVES_PER_EU) void k_pass(const PassPa
     uint32_t wcur = 0, wend = 0;
     uint32_t wbase_q = 0, wbase_h = 0, wbase_p = 0, wbase_f = 0;   // pass 0: first pixel of the wave's current chunk,
     uint64_t wbase_state = 0;                        // its queue entry, global index and master PCG state
+    // throughput body, scene in LDS: a hand-out is SUBS runs of consecutive pixels; lanes 0..SUBS-1 hold one run's base each
+    constexpr uint32_t SUBS = (FAST == 2 && SCENE_LDS) ? (uint32_t)RT_SUBCHUNKS : 1u;   // short launches only: +7 % in the steady state
+    static_assert(SUBS >= 1u && SUBS <= 64u && (SUBS & (SUBS - 1u)) == 0u, "RT_SUBCHUNKS is a power of two");
+    uint32_t sub_q = 0, sub_p = 0, sub_f = 0;
+    uint64_t sub_state = 0;
     bool exhausted = false;
     // diagnostics
     unsigned long long dbg_t0 = 0;
@@ -712,7 +720,25 @@ __global__ __launch_bounds__(RT_BLOCK, RT_WAVES_PER_EU) void k_pass(const PassPa
                     if (b >= n_in) { exhausted = true; break; }
                     wcur = b;
                     wend = (b + chunk < n_in) ? b + chunk : n_in;
-                    if (K_PASS == 0u && K_MODE == 0u) {
+                    if (SUBS > 1u && C->perm_stride != 0u) {
+                        // The 64 entries of a hand-out are SUBS runs of 64 / SUBS consecutive pixels, run i taken from the
+                        // granule 64 / SUBS places further on in the strided order (another stratum of the image: the long
+                        // pixels of one image region do not all end up in one wave).  Entry (granule g, offset r) -> run i =
+                        // r / (64 / SUBS) of granule (g + i * 64 / SUBS) mod G: a bijection of the entries, as g -> g + const is.
+                        // Lanes 0..SUBS-1 prepare one run each: its first pixel and the master PCG there.
+                        wbase_h = b;
+                        const uint32_t G = C->perm_stride << 6;
+                        const uint32_t si = lane & (SUBS - 1u);
+                        uint32_t g2 = (b >> 6) + si * (64u / SUBS);
+                        if (g2 >= G) g2 -= G;
+                        sub_q = perm_entry(g2 << 6, C->perm_stride) + si * (64u / SUBS);
+                        uint32_t f0 = 0, lq0, r0 = 0, c0 = 0;
+                        const bool okq = sub_q < P.n_items;
+                        local_to_global(C, okq ? sub_q : 0u, f0, lq0, r0, c0);
+                        sub_f = f0;
+                        sub_p = r0 * C->width + c0;
+                        sub_state = master_jump(C, C->master_state0, (okq && lane < SUBS) ? sub_p : 0u);
+                    } else if (K_PASS == 0u && K_MODE == 0u) {
                         // master PCG at the chunk's first pixel, on the scalar unit (imagetracer.rs:63-81)
                         wbase_h = b;
                         wbase_q = (uint32_t)__builtin_amdgcn_readfirstlane((int)perm_entry(b, C->perm_stride));
@@ -729,10 +755,28 @@ __global__ __launch_bounds__(RT_BLOCK, RT_WAVES_PER_EU) void k_pass(const PassPa
                 const uint32_t wanted = (uint32_t)__popcll(wantmask);
                 const uint32_t cnt = wanted < avail ? wanted : avail;
                 const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(wantmask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)wantmask, 0u));
+                uint32_t run_q = 0, run_p = 0, run_f = 0;
+                uint64_t run_state = 0;
+                const bool runs = SUBS > 1u && C->perm_stride != 0u;
+                if (runs) {
+                    // every lane reads the run its entry would belong to (the shuffles need the whole wave)
+                    const uint32_t r = (wcur + rank - wbase_h) & 63u;
+                    const uint32_t si = r / (64u / SUBS);
+                    run_q = __shfl(sub_q, si) + (r & (64u / SUBS - 1u));
+                    run_p = __shfl(sub_p, si);
+                    run_f = __shfl(sub_f, si);
+                    run_state = shfl_u64(sub_state, si);
+                }
                 if (lead_want && rank < cnt) {
                     h = wcur + rank;
                     // pass 0: the chunk's entries are consecutive pixels starting at wbase_q
-                    if (K_PASS == 0u && K_MODE == 0u) {
+                    if (runs) {
+                        h = run_q;
+                        my_base_p = run_p;
+                        my_base_f = run_f;
+                        my_base_state = run_state;
+                        if (h >= P.n_items) h = RT_INVALID - 1u;   // ragged end of the strided order: nothing to do
+                    } else if (K_PASS == 0u && K_MODE == 0u) {
                         h = wbase_q + (h - wbase_h);
                         my_base_p = wbase_p;
                         my_base_f = wbase_f;
