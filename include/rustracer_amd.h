@@ -157,8 +157,9 @@ void rt_scene_destroy(rt_scene* scene);
  * where rayon schedules pixels, src/imagetracer.rs:112-123).  A path-traced frame is a sequence of
  * passes: a pixel runs at most budgets[p] rays deep into its recursion in pass p, then its path state
  * is parked in HBM and picked up, compacted into full wavefronts, by pass p+1; the pass after the
- * last budget has no limit.  n_budgets == 0 restores the default (short passes: lowest latency of
- * one frame; launches of more than about a dozen pixels per GPU lane run one pass by themselves);
+ * last budget has no limit.  n_budgets == 0 restores the default: the library chooses (one pass for
+ * path-traced frames of an affine scene of up to 96 shapes from half a pixel per GPU lane on, and for
+ * every launch of more than about a dozen pixels per lane; short passes otherwise);
  * budgets = {0} renders every pixel in one pass (best throughput when several frames are in flight
  * on different streams). */
 int rt_scene_set_schedule(rt_scene* scene, const uint32_t* budgets, uint32_t n_budgets);
