@@ -319,7 +319,7 @@ struct NodeOut {
 #define RT_HELP_MIN 2      // free lanes per speculating lane from which a wave speculates (1 / 2 / 3: 2.26 / 2.24 / 2.37 ms for a 1080p frame)
 #endif
 #ifndef RT_SUBCHUNKS
-#define RT_SUBCHUNKS 4     // FAST == 2: runs of consecutive pixels per 64-entry hand-out (1 / 4 / 8 / 16: 2.33 / 2.07 / 2.11 / 2.02 ms for a 1080p frame)
+#define RT_SUBCHUNKS 4     // FAST == 3: runs of consecutive pixels per 64-entry hand-out (1 / 4 / 8 / 16: 2.33 / 2.07 / 2.11 / 2.02 ms for a 1080p frame)
 #endif
 #ifndef RT_CHUNK
 #define RT_CHUNK 64        // throughput body: pixels per queue hand-out (a divisor of 64)
@@ -352,8 +352,9 @@ __global__ __launch_bounds__(RT_BLOCK, RT_WAVES_PER_EU) void k_pass(const PassPa
                                                    const DMaterial* __restrict__ g_materials,
                                                    const float* __restrict__ texels) {
     extern __shared__ float4 lds_raw[];
-    // FAST == 2: the throughput body with drain helpers, for launches short enough that their end matters (a frame or a few)
-    constexpr bool HELP = (FAST == 2) && (RT_DRAIN_HELPERS != 0);
+    // FAST >= 2: the throughput body with drain helpers once the queue is dry; FAST == 3: mixed hand-outs too, for launches short
+    // enough that their end matters more than the steady state (a frame or a few)
+    constexpr bool HELP_K = (FAST >= 2) && (RT_DRAIN_HELPERS != 0);
     const uint32_t tid = threadIdx.x;
     const uint32_t lane = tid & 63u;
     const uint32_t gtid = blockIdx.x * RT_BLOCK + tid;
@@ -501,7 +502,7 @@ __global__ __launch_bounds__(RT_BLOCK, RT_WAVES_PER_EU) void k_pass(const PassPa
     uint32_t wbase_q = 0, wbase_h = 0, wbase_p = 0, wbase_f = 0;   // pass 0: first pixel of the wave's current chunk,
     uint64_t wbase_state = 0;                        // its queue entry, global index and master PCG state
     // throughput body, scene in LDS: a hand-out is SUBS runs of consecutive pixels; lanes 0..SUBS-1 hold one run's base each
-    constexpr uint32_t SUBS = (FAST == 2 && SCENE_LDS) ? (uint32_t)RT_SUBCHUNKS : 1u;   // short launches only: +7 % in the steady state
+    constexpr uint32_t SUBS = (FAST == 3 && SCENE_LDS) ? (uint32_t)RT_SUBCHUNKS : 1u;   // short launches only: +7 % in the steady state
     static_assert(SUBS >= 1u && SUBS <= 64u && (SUBS & (SUBS - 1u)) == 0u, "RT_SUBCHUNKS is a power of two");
     uint32_t sub_q = 0, sub_p = 0, sub_f = 0;
     uint64_t sub_state = 0;
@@ -884,419 +885,17 @@ __global__ __launch_bounds__(RT_BLOCK, RT_WAVES_PER_EU) void k_pass(const PassPa
             // writes the recursion state directly (no NodeOut record to merge) and a leaf is folded
             // where its value is known.
             // =================================================================================
-            if (K_DEBUG) { dbg_rounds += 1u; dbg_lanes += (uint32_t)__popcll(__ballot(busy)); }
-            u_rays += (uint32_t)__popcll(__ballot(busy));           // every live lane traces one ray per round
-            u_diffuse += (uint32_t)__popcll(__ballot(busy && lvl > 0u && cur_brdf == RT_BRDF_DIFFUSE));
-            u_specular += (uint32_t)__popcll(__ballot(busy && lvl > 0u && cur_brdf != RT_BRDF_DIFFUSE));
-            // siblings of a mirror hit's child resolved in this round, beside the child.  Scenes traced through the hierarchy
-            // keep one child per round: their mirror children rarely end as leaves (measured on the sphere-flake: 452 ms
-            // without, 510 ms with), and the remembered winner (c_hit) already spares them the traversal.
-            // Once the queue is dry (the wave's lanes only drain), every remaining sibling is resolved in the same round: the long
-            // chains of a frame are mirror chains (ten identical rays per mirror hit, each survivor of the roulette skipping twenty
-            // draws), and a sibling costs a few dozen instructions against a round's several hundred.
-            const uint32_t kMirrorSibs = (RT_MIRROR_DRAIN && exhausted && (SCENE_LDS || RT_MIRROR_DRAIN > 1)) ? n_children
-                                         : (SCENE_LDS ? (uint32_t)RT_MIRROR_SIBS : 0u);
-            uint32_t sibs = 0u;
-            // ---- drain helpers ------------------------------------------------------------------------------------------
-            // Once the queue is dry a wave's lanes fall idle one by one while the pixels left run chains of up to
-            // 1 + n + n^2 + ... sequential rays.  Nine in ten of those rays are children of a last-level hit: such a child cannot
-            // open, so after its two scatter draws it consumes `pred` draws (the roulette draw, if any) or pred + 2 n (a survivor's
-            // children draw without tracing, render.rs:137-139, :161).  The PCG state at sibling j is therefore known up to the
-            // number s of survivors before it.  Free lanes (no pixel, nothing pending) take a copy of a speculating lane's
-            // hit and trace (sibling j, s survivors) pairs, slot c = j (j + 1) / 2 + s, at the state jumped by j (2 + pred) + 2 n s
-            // draws; afterwards the owner walks the siblings in order along the pairs that came true and folds their radiances in
-            // sibling order, adopting the PCG state of the last one.  Every draw and every f32 operation is the sequential
-            // recursion's; a pair that did not come true is discarded (and never counted as a ray).
-            uint32_t hT = 0u;                 // candidates per speculating lane this round, its own included (wave-uniform)
-            bool helper = false, spec_own = false;
-            uint32_t h_rank = 0u;             // rank of the speculating lane (its own, or the one this helper works for)
-            uint32_t sv_c = 3u;               // outcome of this lane's candidate: 0 consumed pred, 1 pred + 2n, 2 off the grid, 3 none
-            float sv_r = 0.f, sv_g = 0.f, sv_b = 0.f;
-            const uint32_t h_pred = (P.max_depth >= P.rr_limit) ? 1u : 0u;
-            if (HELP && exhausted && P.max_depth != 0u) {
-                const bool own = busy && lvl == P.max_depth && cur_brdf == RT_BRDF_DIFFUSE && kcount + 2u <= n_children;
-                const bool freel = !busy && q == RT_INVALID;
-                const unsigned long long m_own = __ballot(own), m_free = __ballot(freel);
-                const uint32_t n_own = (uint32_t)__popcll(m_own), n_free = (uint32_t)__popcll(m_free);
-                if (n_own != 0u && n_free >= (uint32_t)RT_HELP_MIN * n_own) {
-                    uint32_t hh = n_free / n_own;
-                    if (hh > 54u) hh = 54u;
-                    hT = hh + 1u;
-                    const uint32_t r_own = __builtin_amdgcn_mbcnt_hi((uint32_t)(m_own >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m_own, 0u));
-                    const uint32_t r_free = __builtin_amdgcn_mbcnt_hi((uint32_t)(m_free >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m_free, 0u));
-                    if (own) lds_wv[r_own] = (uint8_t)lane;
-                    if (freel) lds_wv[64u + r_free] = (uint8_t)lane;
-                    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
-                    __builtin_amdgcn_wave_barrier();
-                    spec_own = own;
-                    h_rank = r_own;
-                    uint32_t h_slot = 0u;
-                    if (freel && r_free < n_own * hh) {
-                        const float inv_hh = 1.0f / (float)hh;
-                        const uint32_t oi = (uint32_t)(((float)r_free + 0.5f) * inv_hh);   // r_free / hh (both below 64)
-                        h_slot = 1u + r_free - oi * hh;
-                        h_rank = oi;
-                        helper = true;
-                    }
-                    // a helper takes a copy of its lane's open hit (every lane runs the shuffles; the others read themselves)
-                    const uint32_t src = helper ? (uint32_t)lds_wv[h_rank] : lane;
-                    const uint64_t g_state = shfl_u64(pstate, src), g_inc = shfl_u64(pinc, src);
-                    const float g0 = __shfl(cw.x, src), g1 = __shfl(cw.y, src), g2 = __shfl(cw.z, src);
-                    const float g3 = __shfl(cv.x, src), g4 = __shfl(cv.y, src), g5 = __shfl(cv.z, src);
-                    const uint32_t g_k = __shfl(kcount, src);
-                    if (helper) {
-                        const uint32_t cj = lds_tri[h_slot], cs = h_slot - cj * (cj + 1u) / 2u;
-                        const uint32_t jd = cj * (2u + h_pred);
-                        if (cj < n_children - g_k && jd < 64u && cs < 16u) {
-                            pinc = g_inc;
-                            pskip = g_inc * P.skip_plus;
-                            uint64_t js = g_state * lds_skip[2u * jd] + g_inc * lds_skip[2u * jd + 1u];
-                            js = js * lds_sv[2u * cs] + g_inc * lds_sv[2u * cs + 1u];
-                            pstate = js;
-                            cw = {g0, g1, g2};
-                            cv = {g3, g4, g5};
-                            cur_brdf = RT_BRDF_DIFFUSE;
-                            lvl = P.max_depth;
-                        } else {
-                            helper = false;       // the pair does not exist for this hit (or lies beyond the jump tables)
-                        }
-                    }
-                }
+            // The body exists twice in the k_pass<..., 2> kernel: the helpers' code in the steady-state rounds costs 4 % (registers,
+            // scheduling), so a wave runs the plain copy until its queue is dry and the copy with drain helpers afterwards.
+            if (HELP_K && exhausted) {
+#define RT_BODY_HELP true
+#include "rt_fast_body.inc"
+#undef RT_BODY_HELP
+            } else {
+#define RT_BODY_HELP false
+#include "rt_fast_body.inc"
+#undef RT_BODY_HELP
             }
-            const bool spec = helper || spec_own;
-#ifdef RT_HELP_DEBUG
-            if (exhausted) { hd_ex += 1u; if (__popcll(__ballot(busy)) <= 16) hd_few += 1u; if (__ballot(busy && lvl == P.max_depth && cur_brdf == RT_BRDF_DIFFUSE) != 0ull) hd_own += 1u; }
-            if (hT != 0u) hd_eng += 1u;
-#endif
-            if (busy || helper) {
-                const uint32_t depth = lvl;                         // Ray.depth (the level-0 ray has depth 0)
-                uint64_t st = pstate;
-                Vec3 o, d;
-                float tmin;
-                if (lvl == 0u) {
-                    // the level-0 ray of sample samp-1 (imagetracer.rs:52-56, :67-75)
-                    ColdParams C = cold_params();
-                    if (RT_DUP_IS(4)) {
-                        uint64_t m2 = mstate;
-                        asm volatile("" : "+v"(m2));
-                        Vec3 o2, d2;
-                        primary_ray<AFFINE>(C, frame_entry(C, px_fr), px_row, px_col, samp - 1u, m2, o2, d2);
-                        RT_KEEP3(o2); RT_KEEP3(d2);
-                    }
-                    primary_ray<AFFINE>(C, frame_entry(C, px_fr), px_row, px_col, samp - 1u, mstate, o, d);
-                    tmin = 1e-5f;                                   // Ray::default (ray.rs:50)
-                } else {
-                    // BRDF::scatter_ray of the next child of the open hit (render.rs:160-166)
-                    const float rf0 = pcg_random_float(st, pinc);
-                    const float rf1 = pcg_random_float(st, pinc);
-                    if (RT_DUP_IS(5)) {
-                        uint64_t s2 = st;
-                        asm volatile("" : "+v"(s2));
-                        const float a2 = pcg_random_float(s2, pinc), b2 = pcg_random_float(s2, pinc);
-                        asm volatile("" ::"v"(a2), "v"(b2), "v"(s2));
-                    }
-                    if (cur_brdf == RT_BRDF_DIFFUSE) {
-                        d = diffuse_scatter_dir(rf0, rf1, cv);
-                        if (RT_DUP_IS(2)) {
-                            Vec3 n2 = cv;
-                            RT_LAUNDER3(n2);
-                            const Vec3 d2 = diffuse_scatter_dir(rf0, rf1, n2);
-                            RT_KEEP3(d2);
-                        }
-                        tmin = 1.0e-3f;                             // material.rs:181
-                    } else {
-                        d = cv;
-                        tmin = 1e-5f;
-                    }
-                    o = cw;
-                }
-                RT_DBG_MARK(1);
-                float t;
-                Vec3 lo, ld;
-                uint32_t bkind;
-                if (RT_DUP_IS(1)) {
-                    Vec3 o2 = o, d2 = d, lo2, ld2;
-                    RT_LAUNDER3(o2); RT_LAUNDER3(d2);
-                    float t2; uint32_t k2;
-                    const int b2 = closest_hit(o2, d2, tmin, __builtin_inff(), t2, lo2, ld2, k2);
-                    RT_KEEP3(lo2); RT_KEEP3(ld2);
-                    asm volatile("" ::"v"(t2), "v"(b2), "v"(k2));
-                }
-                const bool mirror_child = mirror_cache && lvl > 0u && cur_brdf != RT_BRDF_DIFFUSE;
-                const int best = closest_hit(o, d, tmin, __builtin_inff(), t, lo, ld, bkind, mirror_child ? (int)c_hit - 2 : -2);
-                if (mirror_child) c_hit = (uint32_t)(best + 2);
-                RT_DBG_MARK(2);
-                // ---- the hit's colours before the roulette (render.rs:146-148) ----
-                Vec3 hc0 = {0.f, 0.f, 0.f}, em0 = {0.f, 0.f, 0.f};
-                uint32_t sflags = 0u;
-                float hx = 0.f, hy = 0.f, hz = 0.f, lum = 0.f;
-                const bool sphere = (bkind == RT_SHAPE_SPHERE);
-                if (best >= 0) {
-                    const float4* shp = reinterpret_cast<const float4*>(shade + best);
-                    const float4 sh0 = shp[0], sh1 = shp[1];
-                    hc0 = {sh0.x, sh0.y, sh0.z};
-                    em0 = {sh1.x, sh1.y, sh1.z};
-                    sflags = __float_as_uint(sh0.w);
-                    hx = lo.x + ld.x * t; hy = lo.y + ld.y * t; hz = lo.z + ld.z * t;   // inv_ray.at(t)
-                    if (sflags & 6u) {
-                        float u, v;
-                        if (sphere) {
-                            u = rt_atan2f(hy, hx) / 6.2831854820251465f;
-                            v = rt_acosf(hz) / 3.1415927410125732f;
-                            if (u < 0.0f) u += 1.0f;
-                        } else {
-                            u = hx - __builtin_floorf(hx);
-                            v = hy - __builtin_floorf(hy);
-                        }
-                        const DMaterial* M = mats + (SCENE_LDS ? (uint32_t)best : scan[best].material);
-                        if (sflags & 2u) hc0 = pigment_color(&M->brdf_pigment, texels, u, v);
-                        if (sflags & 4u) em0 = pigment_color(&M->emitted, texels, u, v);
-                    }
-                    lum = rt_maxf(hc0.x, rt_maxf(hc0.y, hc0.z));
-                }
-                RT_DBG_MARK(6);
-                // The children of a mirror hit all trace this very ray (SpecularBRDF::scatter_ray ignores its two draws,
-                // src/material.rs:225-246), so World::ray_intersection and the pigments return for each of them what they
-                // returned just now; only the draws differ.  While this child turns out to be a leaf, up to RT_MIRROR_SIBS of
-                // the siblings that follow it are therefore resolved here as well, in order, each consuming its own draws: its
-                // two scatter draws, then the roulette and the rest exactly as below.  A sibling that opens ends the run
-                // (the recursion descends into it); rays and scatters are counted one per child as the reference does.
-                const bool mirror_level = lvl > 0u && cur_brdf != RT_BRDF_DIFFUSE;
-                for (;;) {
-                    bool leaf = true;
-                    bool skipped = false;                           // a survivor at the last level: its children's draws were skipped
-                    float vr, vg, vb;                               // what the ray returns, when it is a leaf
-                    if (best < 0) {
-                        vr = P.bg[0]; vg = P.bg[1]; vb = P.bg[2];   // render.rs:140-143
-                    } else {
-                        Vec3 hc = hc0;
-                        const Vec3 em = em0;
-                        bool alive = true;
-                        const bool roulette = depth >= P.rr_limit;      // render.rs:149-156
-                        float rq = 0.0f;
-                        if (roulette) {
-                            rq = rt_maxf(1.0f - lum, 0.05f);
-                            if (!(pcg_random_float(st, pinc) > rq)) {
-                                vr = em.x; vg = em.y; vb = em.z;
-                                alive = false;
-                            }
-                        }
-                        RT_DBG_MARK(7);
-                        if (alive) {
-                            if (lum > 0.0f && n_children != 0u) {
-                                if (depth + 1u > P.max_depth) {
-                                    // every child returns black without an intersection (render.rs:137-139)
-                                    // but its two scatter draws are consumed (render.rs:161)
-                                    st = st * P.skip_mult + pskip;
-                                    skipped = true;
-                                    // hit_color only meets zeros here: 0 + (hit_color * 1/(1-q)) * 0 is +0 for every
-                                    // finite product, and 1/(1-q) <= 2^24 (q < 1 where the roulette was survived); the
-                                    // survivor's divide is only paid where hit_color is not that tame
-                                    const float big = 1.0e12f;
-                                    const bool tame = __builtin_fabsf(hc.x) < big && __builtin_fabsf(hc.y) < big && __builtin_fabsf(hc.z) < big;
-                                    float cr = 0.0f, cg = 0.0f, cb = 0.0f;
-                                    if (!tame) {
-                                        if (roulette) {
-                                            const float s = 1.0f / (1.0f - rq);
-                                            hc.x = hc.x * s; hc.y = hc.y * s; hc.z = hc.z * s;
-                                        }
-                                        cr = 0.0f + hc.x * 0.0f; cg = 0.0f + hc.y * 0.0f; cb = 0.0f + hc.z * 0.0f;
-                                    }
-                                    vr = em.x + cr * P.inv_num_of_rays;
-                                    vg = em.y + cg * P.inv_num_of_rays;
-                                    vb = em.z + cb * P.inv_num_of_rays;
-                                    RT_DBG_MARK(8);
-                                } else {
-                                    // the hit opens: world_point and normal (src/shape.rs:88-95, :134-138, :175-182,
-                                    // :205-209), then it becomes the current level
-                                    leaf = false;
-                                    if (roulette) {
-                                        const float s = 1.0f / (1.0f - rq);
-                                        hc.x = hc.x * s; hc.y = hc.y * s; hc.z = hc.z * s;
-                                    }
-                                    const Rows3 MW = load_rows(mrows[best].m);
-                                    const Rows3 IW = load_rows(scan[best].inv);
-                                    const Vec3 wp = rows_point<AFFINE>(MW, AFFINE ? nullptr : g_wrows[best].m_w, hx, hy, hz);
-                                    float nx, ny, nz, dp;
-                                    if (sphere) {
-                                        dp = hx * ld.x + hy * ld.y + hz * ld.z;
-                                        nx = hx; ny = hy; nz = hz;
-                                    } else {
-                                        dp = 0.0f * ld.x + 0.0f * ld.y + 1.0f * ld.z;
-                                        nx = 0.0f; ny = 0.0f; nz = 1.0f;
-                                    }
-                                    if (!(dp < 0.0f)) { nx = -nx; ny = -ny; nz = -nz; }
-                                    const Vec3 nrm = rows_normal(IW, nx, ny, nz);
-                                    const uint32_t nbrdf = sflags & 1u;
-                                    // every child of a mirror hit has the same direction (material.rs:225-246)
-                                    const Vec3 ncv = (nbrdf == RT_BRDF_SPECULAR) ? specular_scatter_dir(d, nrm) : nrm;
-                                    if (RT_DUP_IS(3)) {
-                                        float hx2 = hx, hy2 = hy, hz2 = hz;
-                                        asm volatile("" : "+v"(hx2), "+v"(hy2), "+v"(hz2));
-                                        const Rows3 MW2 = load_rows(mrows[best].m);
-                                        const Rows3 IW2 = load_rows(scan[best].inv);
-                                        const Vec3 wp2 = rows_point<AFFINE>(MW2, AFFINE ? nullptr : g_wrows[best].m_w, hx2, hy2, hz2);
-                                        float nx2, ny2, nz2, dp2;
-                                        if (sphere) { dp2 = hx2 * ld.x + hy2 * ld.y + hz2 * ld.z; nx2 = hx2; ny2 = hy2; nz2 = hz2; }
-                                        else { dp2 = 0.0f * ld.x + 0.0f * ld.y + 1.0f * ld.z; nx2 = 0.0f; ny2 = 0.0f; nz2 = 1.0f; }
-                                        if (!(dp2 < 0.0f)) { nx2 = -nx2; ny2 = -ny2; nz2 = -nz2; }
-                                        const Vec3 nrm2 = rows_normal(IW2, nx2, ny2, nz2);
-                                        const Vec3 ncv2 = (nbrdf == RT_BRDF_SPECULAR) ? specular_scatter_dir(d, nrm2) : nrm2;
-                                        RT_KEEP3(wp2); RT_KEEP3(ncv2);
-                                    }
-                                    RT_DBG_MARK(9);
-                                    if (lvl > 0u) {
-                                        kcount += 1u;                   // this child of the level that is saved
-                                        const uint32_t s = lvl - 1u;
-                                        stack.st4(s, 0, make_float4(hc_r, hc_g, hc_b, em_r));
-                                        stack.st4(s, 1, make_float4(em_g, em_b, cu_r, cu_g));
-                                        stack.st4(s, 2, make_float4(cu_b, cw.x, cw.y, cw.z));
-                                        const uint32_t kb = mirror_cache ? (cur_brdf | (kcount << 1) | (c_hit << 9)) : ((kcount << 1) | cur_brdf);
-                                        stack.st4(s, 3, make_float4(cv.x, cv.y, cv.z, __uint_as_float(kb)));
-                                    }
-                                    hc_r = hc.x; hc_g = hc.y; hc_b = hc.z;
-                                    em_r = em.x; em_g = em.y; em_b = em.z;
-                                    cw = wp; cv = ncv;
-                                    cur_brdf = nbrdf;
-                                    c_hit = 0u;
-                                    cu_r = 0.f; cu_g = 0.f; cu_b = 0.f;
-                                    kcount = 0;
-                                    lvl += 1u;
-                                    RT_DBG_MARK(10);
-                                }
-                            } else {
-                                // no children: emitted + 0 * (1/n) (render.rs:157, :171)
-                                vr = em.x + 0.0f * P.inv_num_of_rays;
-                                vg = em.y + 0.0f * P.inv_num_of_rays;
-                                vb = em.z + 0.0f * P.inv_num_of_rays;
-                            }
-                        }
-                    }
-                    pstate = st;
-                    if (!leaf) break;
-                    if (lvl == 0u) {
-                        acc_r = acc_r + vr; acc_g = acc_g + vg; acc_b = acc_b + vb;   // imagetracer.rs:119
-                        busy = false;
-                        break;
-                    }
-                    if (HELP && spec) {
-                        // a candidate of the drain helpers (always a leaf: it was traced at the last level): the walk below folds it
-                        sv_r = vr; sv_g = vg; sv_b = vb;
-                        sv_c = (best < 0) ? (h_pred != 0u ? 2u : 0u) : (skipped ? 1u : 0u);
-                        break;
-                    }
-                    cu_r = cu_r + hc_r * vr; cu_g = cu_g + hc_g * vg; cu_b = cu_b + hc_b * vb;   // render.rs:168
-                    kcount += 1u;
-                    if (!(RT_MIRROR_RUNS && mirror_level && kcount < n_children)) break;
-                    {
-                        // Siblings whose value no draw can change -- the ray leaves the scene, or the hit has no children to
-                        // trace (hit_color_lum == 0) and either no roulette at this depth or an emitted colour that `+ 0`
-                        // leaves alone -- return what this child returned: all of them are folded now, in order, and the
-                        // pixel's PCG jumps over their draws (2 scatter draws each, 3 with the roulette draw).
-                        const bool roul = (best >= 0) && (depth >= P.rr_limit);
-                        const uint32_t e0 = __float_as_uint(em0.x), e1 = __float_as_uint(em0.y), e2 = __float_as_uint(em0.z);
-                        const bool plain = (e0 & 0x7FFFFFFFu) <= 0x7F800000u && e0 != 0x80000000u && (e1 & 0x7FFFFFFFu) <= 0x7F800000u &&
-                                           e1 != 0x80000000u && (e2 & 0x7FFFFFFFu) <= 0x7F800000u && e2 != 0x80000000u;
-                        const uint32_t r = n_children - kcount;
-                        const uint32_t nd = r * (roul ? 3u : 2u);
-                        if (((best < 0) || (!(lum > 0.0f) && (!roul || plain))) && nd < 64u) {
-                            st = st * lds_skip[2u * nd] + pinc * lds_skip[2u * nd + 1u];
-                            pstate = st;
-                            const float pr = hc_r * vr, pg = hc_g * vg, pb = hc_b * vb;   // render.rs:168, the same product every time
-                            for (uint32_t i = 0; i < r; ++i) { cu_r = cu_r + pr; cu_g = cu_g + pg; cu_b = cu_b + pb; }
-                            kcount = n_children;
-                            sibs += r;
-                            break;
-                        }
-                    }
-                    if (sibs >= kMirrorSibs) break;
-                    sibs += 1u;
-                    (void)pcg_random(st, pinc);                     // the sibling's scatter draws (render.rs:161)
-                    (void)pcg_random(st, pinc);
-                }
-                RT_DBG_MARK(4);
-            }
-            if (HELP && hT != 0u) {
-                // the walk (every lane runs the shuffles: a lane that is switched off cannot be read)
-                uint32_t wj = 0u, wsv = 0u, extra = 0u;
-                bool walking = spec_own;
-                const uint32_t hbase = 64u + h_rank * (hT - 1u) - 1u;
-                for (;;) {
-                    uint32_t src = lane;
-                    if (walking && wj != 0u) {
-                        const uint32_t c = wj * (wj + 1u) / 2u + wsv;
-                        if (c < hT) src = (uint32_t)lds_wv[hbase + c];
-                        else walking = false;                       // nobody traced this pair
-                    }
-                    if (__ballot(walking) == 0ull) break;
-                    const float gr = __shfl(sv_r, src), gg = __shfl(sv_g, src), gb = __shfl(sv_b, src);
-                    const uint32_t gc = __shfl(sv_c, src);
-                    const uint64_t gs = shfl_u64(pstate, src);
-                    if (walking) {
-                        if (gc == 3u) {
-                            walking = false;                        // the pair was not traced
-                        } else {
-                            cu_r = cu_r + hc_r * gr; cu_g = cu_g + hc_g * gg; cu_b = cu_b + hc_b * gb;   // render.rs:168
-                            kcount += 1u;
-                            pstate = gs;
-                            if (wj != 0u) extra += 1u;
-                            if (gc == 1u) wsv += 1u;
-                            else if (gc == 2u) walking = false;     // a ray that left the scene drew nothing: off the grid
-                            wj += 1u;
-                            if (kcount == n_children) walking = false;
-                        }
-                    }
-                }
-                // the siblings taken from helpers are rays and diffuse scatters of the reference like any other
-#pragma unroll
-                for (int off = 32; off > 0; off >>= 1) extra += __shfl_xor(extra, off);
-                extra = (uint32_t)__builtin_amdgcn_readfirstlane((int)extra);
-                u_rays += extra;
-                u_diffuse += extra;
-#ifdef RT_HELP_DEBUG
-                u_shared += extra;
-#endif
-            }
-            {
-                if (busy && lvl > 0u) {
-                    // levels whose children have all returned close and return to their parent
-                    while (kcount == n_children) {
-                        const float wr = em_r + cu_r * P.inv_num_of_rays;   // render.rs:171
-                        const float wg = em_g + cu_g * P.inv_num_of_rays;
-                        const float wb = em_b + cu_b * P.inv_num_of_rays;
-                        lvl -= 1u;
-                        if (lvl == 0u) {
-                            acc_r = acc_r + wr; acc_g = acc_g + wg; acc_b = acc_b + wb;   // imagetracer.rs:119
-                            busy = false;
-                            break;
-                        }
-                        const uint32_t s = lvl - 1u;
-                        const float4 s0 = stack.ld4(s, 0), s1 = stack.ld4(s, 1), s2 = stack.ld4(s, 2), s3 = stack.ld4(s, 3);
-                        hc_r = s0.x; hc_g = s0.y; hc_b = s0.z;
-                        em_r = s0.w; em_g = s1.x; em_b = s1.y;
-                        cu_r = s1.z; cu_g = s1.w; cu_b = s2.x;
-                        cw.x = s2.y; cw.y = s2.z; cw.z = s2.w;
-                        cv.x = s3.x; cv.y = s3.y; cv.z = s3.z;
-                        const uint32_t kb = __float_as_uint(s3.w);
-                        kcount = mirror_cache ? ((kb >> 1) & 0xFFu) : (kb >> 1);
-                        cur_brdf = kb & 1u;
-                        c_hit = mirror_cache ? (kb >> 9) : 0u;
-                        cu_r = cu_r + hc_r * wr; cu_g = cu_g + hc_g * wg; cu_b = cu_b + hc_b * wb;   // render.rs:168
-                    }
-                    RT_DBG_MARK(11);
-                }
-            }
-            // every sibling resolved above was one more ray and one more mirror scatter (counted with the whole wave active)
-            if (RT_MIRROR_RUNS && __ballot(sibs != 0u) != 0ull) {
-                uint32_t c = sibs;
-#pragma unroll
-                for (int off = 32; off > 0; off >>= 1) c += __shfl_xor(c, off);
-                c = (uint32_t)__builtin_amdgcn_readfirstlane((int)c);
-                u_rays += c;
-                u_specular += c;
-                u_shared += c;
-            }
-            RT_DBG_MARK(5);
             continue;
         }
 
