@@ -113,6 +113,7 @@ struct PassParams {
     uint32_t n_items;                // n_frames * (pixels of this part) / solve items
     uint32_t n_in0;                  // length of pass 0's (virtual) queue: n_items, or whole 64-pixel granules
     uint32_t perm_stride;            // 0, or granules per stratum of the pass-0 queue order (see perm_entry)
+    uint32_t mix_from;               // FAST == 3: hand-outs from this granule of the queue on are mixed (runs from several strata)
     // solve mode
     const rt_ray* in_rays;
     rt_pcg* io_pcgs;
@@ -505,6 +506,7 @@ __global__ __launch_bounds__(RT_BLOCK, RT_WAVES_PER_EU) void k_pass(const PassPa
     constexpr uint32_t SUBS = (FAST == 3 && SCENE_LDS) ? (uint32_t)RT_SUBCHUNKS : 1u;   // short launches only: +7 % in the steady state
     static_assert(SUBS >= 1u && SUBS <= 64u && (SUBS & (SUBS - 1u)) == 0u, "RT_SUBCHUNKS is a power of two");
     uint32_t sub_q = 0, sub_p = 0, sub_f = 0;
+    bool wmix = false;                               // the wave's current hand-out is a mixed one
     uint64_t sub_state = 0;
     bool exhausted = false;
     // diagnostics
@@ -721,17 +723,19 @@ __global__ __launch_bounds__(RT_BLOCK, RT_WAVES_PER_EU) void k_pass(const PassPa
                     if (b >= n_in) { exhausted = true; break; }
                     wcur = b;
                     wend = (b + chunk < n_in) ? b + chunk : n_in;
-                    if (SUBS > 1u && C->perm_stride != 0u) {
+                    wmix = SUBS > 1u && C->perm_stride != 0u && (b >> 6) >= C->mix_from;
+                    if (SUBS > 1u && wmix) {
                         // The 64 entries of a hand-out are SUBS runs of 64 / SUBS consecutive pixels, run i taken from the
                         // granule 64 / SUBS places further on in the strided order (another stratum of the image: the long
                         // pixels of one image region do not all end up in one wave).  Entry (granule g, offset r) -> run i =
                         // r / (64 / SUBS) of granule (g + i * 64 / SUBS) mod G: a bijection of the entries, as g -> g + const is.
+                        // Only the end of the queue is mixed, granules [mix_from, G) among themselves (the pixels in flight when
+                        // the queue runs dry are the ones handed out last; mixing costs the steady state 7 %).
                         // Lanes 0..SUBS-1 prepare one run each: its first pixel and the master PCG there.
                         wbase_h = b;
-                        const uint32_t G = C->perm_stride << 6;
+                        const uint32_t G0 = C->mix_from, Gt = (C->perm_stride << 6) - G0;
                         const uint32_t si = lane & (SUBS - 1u);
-                        uint32_t g2 = (b >> 6) + si * (64u / SUBS);
-                        if (g2 >= G) g2 -= G;
+                        const uint32_t g2 = G0 + (((b >> 6) - G0) + si * (64u / SUBS)) % Gt;
                         sub_q = perm_entry(g2 << 6, C->perm_stride) + si * (64u / SUBS);
                         uint32_t f0 = 0, lq0, r0 = 0, c0 = 0;
                         const bool okq = sub_q < P.n_items;
@@ -758,7 +762,7 @@ __global__ __launch_bounds__(RT_BLOCK, RT_WAVES_PER_EU) void k_pass(const PassPa
                 const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(wantmask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)wantmask, 0u));
                 uint32_t run_q = 0, run_p = 0, run_f = 0;
                 uint64_t run_state = 0;
-                const bool runs = SUBS > 1u && C->perm_stride != 0u;
+                const bool runs = SUBS > 1u && wmix;
                 if (runs) {
                     // every lane reads the run its entry would belong to (the shuffles need the whole wave)
                     const uint32_t r = (wcur + rank - wbase_h) & 63u;

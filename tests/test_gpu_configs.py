@@ -311,7 +311,7 @@ def test_mirror_children_runs_and_their_exactness_conditions(n, d, rr_limit, mon
 def test_drain_helpers_and_same_round_mirror_siblings_are_exact(n, d, rr_limit, helpers, monkeypatch):
     """Once the queue is dry the throughput body (k_pass FAST) (a) resolves all remaining siblings of a mirror hit's leaf child
     in one round and (b) lets free lanes trace later siblings of another lane's last-level diffuse hit at speculated PCG
-    offsets (kernel variants 2 and 3; 3 also mixes its hand-outs; 1 is the plain body: `RUSTRACER_FAST_VARIANT`).  All must reproduce the
+    offsets (kernel variants 2 and 3; 3 also mixes the queue's last hand-outs; 1 is the plain body: `RUSTRACER_FAST_VARIANT`).  All must reproduce the
     sequential recursion bit for bit: with a roulette draw at the last level (rr_limit <= max_depth) and without, with
     rays that leave the scene (no sky: they draw nothing, which takes a sibling off the speculated grid), with more
     children than the jump tables cover (n = 30), a single child (nothing to speculate) and every counter equal."""
