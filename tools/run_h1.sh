@@ -1,12 +1,10 @@
 set -e
-timeout -k 10 900 python -u -m pytest tests/ -x -q -m gpu --timeout 300 --timeout-method thread > gpurun_out/h16_tests.txt 2>&1 || { tail -40 gpurun_out/h16_tests.txt; exit 1; }
-tail -3 gpurun_out/h16_tests.txt
-BENCH_ARGS="--steps 20 --warmup 5 --no-call-timing" bash tools/prof.sh > gpurun_out/r2j_prof_steps20.txt 2>&1 || { tail -20 gpurun_out/r2j_prof_steps20.txt; exit 1; }
-tail -32 gpurun_out/r2j_prof_steps20.txt
-timeout -k 10 300 python bench.py > gpurun_out/r2j_bench_default.json 2> gpurun_out/r2j_bench_default.err
-timeout -k 10 300 python bench.py --steps 20 --warmup 5 > gpurun_out/r2j_bench_steps20.json 2> gpurun_out/r2j_bench_steps20.err
-python -c "
-import json
-for f in ('default','steps20'):
-    d=json.load(open(f'gpurun_out/r2j_bench_{f}.json')); print(f, d['ms_per_step'], d['value'], d['roofline']['achieved'], d['roofline']['frac'], d['roofline']['frac_of_measured_nofma_ceiling'], d['roofline']['achieved_executed'], d['roofline']['frac_executed_of_measured_nofma_ceiling'], d['call']['call_ms'], d['call']['frame_ms_resident'], d['config']['region_ms'])
-"
+export RUSTRACER_AMD_SO=$PWD/tools/dbg/hbm.so
+RUSTRACER_HBM_HELPERS=1 timeout -k 10 600 python -u -m pytest tests/test_gpu_parity.py tests/test_gpu_configs.py -x -q -m gpu --timeout 300 --timeout-method thread -k "c4 or c5 or hierarchy or random_scenes or flake" > gpurun_out/h18_tests.txt 2>&1 || { tail -30 gpurun_out/h18_tests.txt; exit 1; }
+tail -2 gpurun_out/h18_tests.txt
+for h in "" 1 "" 1; do
+if [ -n "$h" ]; then export RUSTRACER_HBM_HELPERS=1; else unset RUSTRACER_HBM_HELPERS; fi
+echo "helpers=[$h]"
+timeout -k 10 200 python bench.py --config c5 --width 1920 --height 1080 --aa 4 --steps 1 --warmup 1 --repeats 3 --no-cpu-baseline 2>/dev/null | python -c "import json,sys; d=json.loads(sys.stdin.read()); print('c5 1080p aa4', d['config']['schedule'], [round(x,1) for x in d['config']['region_ms']])" | tee -a gpurun_out/h18_c5.txt
+timeout -k 10 200 python bench.py --config c4 --width 1920 --height 1080 --steps 1 --warmup 1 --repeats 3 --no-cpu-baseline 2>/dev/null | python -c "import json,sys; d=json.loads(sys.stdin.read()); print('c4 1080p', d['config']['schedule'], [round(x,1) for x in d['config']['region_ms']])" | tee -a gpurun_out/h18_c5.txt
+done
