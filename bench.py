@@ -41,8 +41,8 @@ PEAK_MEASURED_NOFMA_TFLOPS = 61.6
 PEAK_MEASURED_NOFMA_SOURCE = "profiles/r01_valu_microbench.txt"
 # HBM bytes per c3 frame from rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes, gfx950 corrections of
 # MI355X_MICROARCH.md applied); see TRAFFIC_SOURCE.  Only reported for the configuration that was profiled.
-TRAFFIC_BYTES_PER_FRAME_C3 = (2 * 295.1 + 401630) * 1000 * 7 / 106     # 7 dispatches, 106 frames: 26.5 MB per frame
-TRAFFIC_SOURCE = "profiles/r02h_rocprof_steps20.txt (1 GPU, c3, one-pass launches)"
+TRAFFIC_BYTES_PER_FRAME_C3 = (2 * 295.56 + 401630) * 1000 * 7 / 106     # 7 dispatches, 106 frames: 26.5 MB per frame
+TRAFFIC_SOURCE = "profiles/r02i_rocprof_steps20.txt (1 GPU, c3, one-pass launches)"
 
 
 def partition_rows(height, part, n_parts, tile_rows):

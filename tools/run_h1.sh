@@ -1,5 +1,12 @@
 set -e
-timeout -k 10 300 python -u -m pytest tests/test_gpu_parity.py tests/test_gpu_configs.py -x -q -m gpu --timeout 120 --timeout-method thread -k "c3_pathtracer_demo_small or parameter_corners or aa2_other or headline_frame or render_frames or row_tile or drain_helpers or diagonal or random_scenes" > gpurun_out/h20_tests.txt 2>&1 || { tail -30 gpurun_out/h20_tests.txt; exit 1; }
-tail -2 gpurun_out/h20_tests.txt
-STEPS=20 tools/ab3.sh nounit unit nounit unit | tee gpurun_out/h20_ab20.txt
-STEPS=240 tools/ab3.sh nounit unit | tee gpurun_out/h20_ab240.txt
+timeout -k 10 900 python -u -m pytest tests/ -x -q -m gpu --timeout 300 --timeout-method thread > gpurun_out/h24_tests.txt 2>&1 || { tail -40 gpurun_out/h24_tests.txt; exit 1; }
+tail -3 gpurun_out/h24_tests.txt
+BENCH_ARGS="--steps 20 --warmup 5 --no-call-timing" bash tools/prof.sh > gpurun_out/r2l_prof_steps20.txt 2>&1 || { tail -20 gpurun_out/r2l_prof_steps20.txt; exit 1; }
+tail -32 gpurun_out/r2l_prof_steps20.txt
+timeout -k 10 300 python bench.py > gpurun_out/r2l_bench_default.json 2> gpurun_out/r2l_bench_default.err
+timeout -k 10 300 python bench.py --steps 20 --warmup 5 > gpurun_out/r2l_bench_steps20.json 2> gpurun_out/r2l_bench_steps20.err
+python -c "
+import json
+for f in ('default','steps20'):
+    d=json.load(open(f'gpurun_out/r2l_bench_{f}.json')); print(f, d['ms_per_step'], d['value'], d['roofline']['achieved'], d['roofline']['frac'], d['roofline']['frac_of_measured_nofma_ceiling'], d['roofline']['achieved_executed'], d['roofline']['frac_executed_of_measured_nofma_ceiling'], d['call']['call_ms'], d['call']['frame_ms_resident'], d['config']['region_ms'])
+"
