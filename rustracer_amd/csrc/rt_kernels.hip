@@ -323,7 +323,8 @@ struct NodeOut {
 #define RT_SUBCHUNKS 4     // FAST == 3: runs of consecutive pixels per 64-entry hand-out (1 / 4 / 8 / 16: 2.33 / 2.07 / 2.11 / 2.02 ms for a 1080p frame)
 #endif
 #ifndef RT_CHUNK
-#define RT_CHUNK 64        // throughput body: pixels per queue hand-out (a divisor of 64)
+#define RT_CHUNK 64        // throughput body: pixels per queue hand-out (a divisor of 64; 16 / 8: 2.4x / 5x slower, every refill
+                           // then waits for an atomic round trip)
 #endif
 #ifndef RT_MIRROR_DRAIN
 #define RT_MIRROR_DRAIN 1  // throughput body, queue dry: all siblings of a mirror hit's leaf child in one round (2: hierarchy scenes too)
