@@ -336,3 +336,10 @@ def test_drain_helpers_and_same_round_mirror_siblings_are_exact(n, d, rr_limit, 
         assert_bit_equal(g.cpu().numpy(), ref, f"kernel variant {helpers}, sky={with_sky}, n={n} d={d} rr={rr_limit}")
         for k in COUNTERS:
             assert gs[k] == rs[k], (with_sky, k, gs[k], rs[k])
+    if (n, d, rr_limit) == (10, 3, 3):
+        # antialiased: a lane between two samples of its pixel holds state (master PCG, accumulator) and is no free lane
+        ref, rs = oracle(world, cam, rr, 64, 40, aa=3)
+        g, gs = gpu_render(world, cam, rr, 64, 40, aa=3, schedule=(0,))
+        assert_bit_equal(g.cpu().numpy(), ref, f"kernel variant {helpers}, aa=3")
+        for k in COUNTERS:
+            assert gs[k] == rs[k], ("aa=3", k, gs[k], rs[k])
