@@ -498,6 +498,7 @@ __global__ __launch_bounds__(RT_BLOCK, RT_WAVES_PER_EU) void k_pass(const PassPa
     // counters (kept by the team leader)
     uint32_t n_rays = 0, n_samples = 0, n_diffuse = 0, n_specular = 0;
     uint32_t u_rays = 0, u_samples = 0, u_diffuse = 0, u_specular = 0, u_shared = 0;   // FAST: the same, wave-uniform (ballot counts)
+    uint32_t l_sibs = 0, l_extra = 0;   // FAST, per lane: mirror siblings resolved beside their first child / siblings taken from drain helpers
 
     // wave-private slice of the input queue
     uint32_t wcur = 0, wend = 0;
@@ -1164,6 +1165,14 @@ __global__ __launch_bounds__(RT_BLOCK, RT_WAVES_PER_EU) void k_pass(const PassPa
             if (lane == 0 && v != 0u) atomicAdd(&P.ctl->counters[j], (unsigned long long)v);
         };
         if (FAST) {
+            // per-lane counts: siblings of a mirror hit's child (a ray, a mirror scatter, answered from the sibling's query)
+            // and siblings taken from drain helpers (a ray, a diffuse scatter)
+#pragma unroll
+            for (int off = 32; off > 0; off >>= 1) { l_sibs += __shfl_down(l_sibs, off); l_extra += __shfl_down(l_extra, off); }
+            u_rays += l_sibs + l_extra;
+            u_specular += l_sibs;
+            u_shared += l_sibs;
+            u_diffuse += l_extra;
             if (lane == 0) {
                 if (u_rays) atomicAdd(&P.ctl->counters[0], (unsigned long long)u_rays);
                 if (u_samples) atomicAdd(&P.ctl->counters[1], (unsigned long long)u_samples);
