@@ -39,10 +39,28 @@ PEAK_STRICT_NOFMA_TFLOPS = 78.6     # same issue rate with unfused mul/add (the 
 # what tools/valu_bench.hip sustains on the box with unfused v_mul_f32 + v_add_f32 streams (profiles/r01_valu_microbench.txt)
 PEAK_MEASURED_NOFMA_TFLOPS = 61.6
 PEAK_MEASURED_NOFMA_SOURCE = "profiles/r01_valu_microbench.txt"
-# HBM bytes per c3 frame from rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes, gfx950 corrections of
-# MI355X_MICROARCH.md applied); see TRAFFIC_SOURCE.  Only reported for the configuration that was profiled.
-TRAFFIC_BYTES_PER_FRAME_C3 = (2 * 295.56 + 401630) * 1000 * 7 / 106     # 7 dispatches, 106 frames: 26.5 MB per frame
-TRAFFIC_SOURCE = "profiles/r02i_rocprof_steps20.txt (1 GPU, c3, one-pass launches)"
+
+
+def profiled_traffic_c3():
+    """HBM bytes per c3 frame from the newest rocprofv3 summary under profiles/ (`*rocprof_steps*.txt`, written by
+    tools/prof.sh + tools/prof_summary.py): FETCH_SIZE and WRITE_SIZE are KB per k_pass dispatch from separate --pmc
+    passes; gfx950 correction of MI355X_MICROARCH.md (FETCH_SIZE reports half the bytes of wide reads) applied; the
+    summary states how many frames its dispatches rendered.  Returns (bytes per frame, file) or (None, None).  Only
+    reported for the configuration that was profiled (1 GPU, c3, one-pass launches)."""
+    import glob
+    import re
+    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "*rocprof_steps*.txt")), reverse=True):
+        try:
+            text = open(path).read()
+        except OSError:
+            continue
+        fetch = re.search(r"FETCH_SIZE\s+mean/dispatch\s+([0-9.e+-]+)\s+dispatches\s+(\d+)", text)
+        write = re.search(r"WRITE_SIZE\s+mean/dispatch\s+([0-9.e+-]+)\s+dispatches\s+(\d+)", text)
+        frames = re.search(r"(\d+) frames over the (\d+) dispatches", text)
+        if fetch and write and frames and int(frames.group(2)) == int(fetch.group(2)) == int(write.group(2)):
+            kb = 2.0 * float(fetch.group(1)) + float(write.group(1))
+            return kb * 1000.0 * int(frames.group(2)) / int(frames.group(1)), os.path.relpath(path, ROOT)
+    return None, None
 
 
 def partition_rows(height, part, n_parts, tile_rows):
@@ -192,6 +210,12 @@ def main():
                          "profiles/r02_remote_store_probe.jsonl).  p2p: parts rendered locally, pushed with device-to-device "
                          "copies (copy engines, beside the next launch's render).  rccl: one gather collective per launch.  Each "
                          "falls back to the next when the handle cannot be exchanged")
+    ap.add_argument("--force-dist", action="store_true",
+                    help="run the N-rank code path even with one rank (torch.distributed.run --nproc-per-node 1): the process group "
+                         "forms (nccl = RCCL), parts are gathered with the collective and assembled by rt_unpack_parts / placed by "
+                         "rank 0 exactly as with N > 1.  What one GPU can execute of the multi-GPU transport")
+    ap.add_argument("--no-strong-leg", action="store_true",
+                    help="N > 1, weak scaling: skip the extra strong-scaling leg (the same frames split by row tiles over the ranks)")
     ap.add_argument("--verify", action="store_true",
                     help="after the run, rank 0 compares every assembled image it still holds with a whole-frame render, bit for bit")
     args = ap.parse_args()
@@ -218,7 +242,10 @@ def main():
     lib = _abi.lib()
     _abi.check(lib.rt_init(device))
     N = world_size
-    if N > 1:
+    D = N > 1 or args.force_dist                     # the distributed code path (process group, gather, placement by rank 0)
+    if args.force_dist and "RANK" not in os.environ:
+        raise SystemExit("--force-dist needs the rendezvous environment: launch with torch.distributed.run --nproc-per-node 1")
+    if D:
         if args.dist_backend == "nccl":
             dist.init_process_group("nccl", device_id=torch.device("cuda", device))
         else:
@@ -234,7 +261,7 @@ def main():
     rr = ra.PathTracer(scene, ra.BLACK, NUM_OF_RAYS, MAX_DEPTH, RR_LIMIT).flatten()
     dev = scene.device()          # World resident in HBM before the timed region
     headline = c3 and (WIDTH, HEIGHT, AA) == (1920, 1080, 1)
-    weak = N > 1 and (args.scaling == "weak" or (args.scaling == "auto" and c3))
+    weak = D and (args.scaling == "weak" or (args.scaling == "auto" and c3))
     if weak and HEIGHT % N != 0:
         raise SystemExit(f"weak scaling uses {N} equal row blocks: height {HEIGHT} is not divisible by {N}")
     fpstep = N if weak else 1                       # frames per step
@@ -243,7 +270,7 @@ def main():
     # streams and launch sizes: one stream on one GPU (a launch of this size fills the GPU by itself, and launches that
     # share it run slower than one after the other); several GPUs: two, so that one launch's drain of long pixels
     # overlaps the next launch's bulk, and the copies of a launch run beside the next render
-    F = max(1, min(args.inflight, 4)) if args.inflight else (2 if (N > 1 and args.gather != "direct") else 1)
+    F = max(1, min(args.inflight, 4)) if args.inflight else (2 if (D and args.gather != "direct") else 1)
     total_frames = steps * fpstep
     if args.frames_per_launch:
         B = max(1, min(args.frames_per_launch, 1024))
@@ -253,7 +280,7 @@ def main():
         # the fewest launches of at most 128 frames' worth of work per GPU (every launch ends with one drain of long pixels)
         cap = 128 * fpstep
         n_l = (total_frames + cap - 1) // cap
-        if N > 1 and args.gather != "direct":
+        if D and args.gather != "direct":
             n_l = max(n_l, min(4, steps))            # copies of one launch run beside the next launch's render
         B = max(1, min((total_frames + n_l - 1) // n_l, cap))
     if weak:
@@ -272,7 +299,7 @@ def main():
 
     def sync_all():
         torch.cuda.synchronize()
-        if N > 1:
+        if D:
             dist.barrier()
             torch.cuda.synchronize()
 
@@ -281,7 +308,7 @@ def main():
     # --------------------------------------------------------------------------------------------------------------
     cpu_group = None
     p2p = False
-    if N > 1:
+    if D:
         cpu_group = dist.new_group(backend="gloo") if args.dist_backend == "nccl" else dist.group.WORLD
 
     def share_from_rank0(make, kernel_stores=False):
@@ -327,7 +354,7 @@ def main():
     direct = False
     ring = 0
     images = None
-    if N > 1 and args.gather == "direct":
+    if D and args.gather == "direct":
         # ---- every rank's kernel stores its pixels in place in rank 0's final images (rt_partition.in_place) ----
         ring = min(max(total_frames, warmup * fpstep, N), max(2 * B, int(32e9 // frame_bytes)))
         ring = max(B, ring // B * B)                 # whole launches: a launch never straddles the wrap
@@ -468,7 +495,7 @@ def main():
         stride = max(sizes_px)
         remote, NB = None, F
         bufs = gathered = None
-        if N > 1:
+        if D:
             bufs = [torch.zeros((B, stride, 3), dtype=torch.float32, device="cuda") for _ in range(F)]
             if args.gather == "p2p":
                 # two more sets of gathered / image buffers than launches in flight, so that a part pushed by launch l lands
@@ -481,11 +508,11 @@ def main():
                         gathered = shared
             if remote is None and rank == 0:
                 gathered = [torch.zeros((N, B, stride, 3), dtype=torch.float32, device="cuda") for _ in range(F)]
-        images = [torch.zeros((B, HEIGHT, WIDTH, 3), dtype=torch.float32, device="cuda") for _ in range(NB)] if rank == 0 or N == 1 else None
+        images = [torch.zeros((B, HEIGHT, WIDTH, 3), dtype=torch.float32, device="cuda") for _ in range(NB)] if rank == 0 else None
         copy_done, unpack_done = {}, {}
 
         def out_ptrs(slot, n):
-            t = bufs[slot] if N > 1 else images[slot]
+            t = bufs[slot] if D else images[slot]
             return (C.c_void_p * n)(*[t[b].data_ptr() for b in range(n)])
 
         def launch(l, n, ev=None, stats=None):
@@ -504,7 +531,7 @@ def main():
                     remote[l % NB][rank, :n].copy_(bufs[slot][:n], non_blocking=True)
                     copy_done[l] = torch.cuda.Event()
                     copy_done[l].record(st)
-                elif N > 1:
+                elif D:
                     # the collective runs on RCCL's stream after st's render; work.wait() makes st (not the host) wait for
                     # it, so the slot's buffers are free again when st reaches its next launch
                     if args.dist_backend == "gloo":
@@ -583,7 +610,7 @@ def main():
         regions.append((dt, span_ms / n_launches, latency_ms))
     t = torch.tensor([[r[0] for r in regions], [r[1] for r in regions], [r[2] for r in regions]], dtype=torch.float64, device="cuda")
     rays_t = torch.tensor([float(my_rays_per_frame)], dtype=torch.float64, device="cuda")
-    if N > 1:
+    if D:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)      # every region: the slowest rank's clock
         dist.all_reduce(rays_t, op=dist.ReduceOp.SUM)
     region_s = [float(x) for x in t[0]]
@@ -617,12 +644,99 @@ def main():
         print(f"verify ok: {checked} images bit-identical to a whole-frame render{how}", file=sys.stderr)
 
     # --------------------------------------------------------------------------------------------------------------
+    # N > 1, weak scaling: the strong-scaling definition beside it (north_star's "row-tile scaling efficiency" of a fixed
+    # frame): the same K frames, every frame's 1-row tiles dealt round-robin over the ranks, pixels to rank 0 by the same
+    # transport (in place through the IPC mapping, else one gather per launch + rt_unpack_parts)
+    # --------------------------------------------------------------------------------------------------------------
+    strong = None
+    if weak and not args.no_strong_leg:
+        s_part = _abi.rt_partition(rank, N, args.tile_rows, 0, 1 if direct else 0)
+        nS = min(B, steps)                               # frames per launch (a step is ONE frame here)
+        s_cams = (_abi.rt_camera * nS)(*([cam] * nS))
+        s_st = streams[0]
+        s_buf = s_gath = s_out = None
+        if not direct:
+            s_sizes = [lib.rt_partition_pixels(WIDTH, HEIGHT, C.byref(_abi.rt_partition(p, N, args.tile_rows, 0, 0))) for p in range(N)]
+            s_stride = max(s_sizes)
+            s_buf = torch.zeros((nS, s_stride, 3), dtype=torch.float32, device="cuda")
+            if rank == 0:
+                s_gath = torch.zeros((N, nS, s_stride, 3), dtype=torch.float32, device="cuda")
+                s_out = torch.zeros((nS, HEIGHT, WIDTH, 3), dtype=torch.float32, device="cuda")
+
+        def s_launch(f0, n):
+            with torch.cuda.stream(s_st):
+                if direct:
+                    ptrs = [images[(f0 + b) % ring].data_ptr() for b in range(n)]
+                else:
+                    ptrs = [s_buf[b].data_ptr() for b in range(n)]
+                _abi.check(lib.rt_render_frames(dev.handle, s_cams, n, C.byref(rr), WIDTH, HEIGHT, INIT_STATE, INIT_SEQ, AA,
+                                                C.byref(s_part), (C.c_void_p * n)(*ptrs), s_st.cuda_stream, None))
+                if direct:
+                    return
+                if args.dist_backend == "gloo":
+                    host = s_buf.cpu()
+                    hlist = [torch.empty_like(host) for _ in range(N)] if rank == 0 else None
+                    dist.gather(host, gather_list=hlist, dst=0)
+                    if rank == 0:
+                        s_gath.copy_(torch.stack(hlist))
+                elif rank == 0:
+                    dist.gather(s_buf, gather_list=list(s_gath.unbind(0)), dst=0, async_op=True).wait()
+                else:
+                    dist.gather(s_buf, dst=0, async_op=True).wait()
+                if rank == 0:
+                    for b in range(n):
+                        _abi.check(lib.rt_unpack_parts(s_gath[0, b].data_ptr(), nS * s_stride, N, args.tile_rows, WIDTH, HEIGHT,
+                                                       s_out[b].data_ptr(), s_st.cuda_stream))
+
+        def s_run(n_frames):
+            f0 = 0
+            while f0 < n_frames:
+                n = min(nS, n_frames - f0)
+                if direct and f0 > 0 and f0 % ring == 0:
+                    sync_all()
+                s_launch(f0, n)
+                f0 += n
+
+        s_run(min(nS, max(1, warmup)))
+        sync_all()
+        s_regions = []
+        for _ in range(min(repeats, 3)):
+            sync_all()
+            t0 = time.perf_counter()
+            s_run(steps)
+            sync_all()
+            s_regions.append(time.perf_counter() - t0)
+        ts = torch.tensor(s_regions, dtype=torch.float64, device="cuda")
+        dist.all_reduce(ts, op=dist.ReduceOp.MAX)
+        s_sorted = sorted(float(x) for x in ts)
+        s_dt = s_sorted[(len(s_sorted) - 1) // 2]
+        if args.verify and rank == 0:
+            ref = torch.zeros((HEIGHT, WIDTH, 3), dtype=torch.float32, device="cuda")
+            _abi.check(lib.rt_render(dev.handle, C.byref(cam), C.byref(rr), WIDTH, HEIGHT, INIT_STATE, INIT_SEQ, AA, None,
+                                     ref.data_ptr(), torch.cuda.current_stream().cuda_stream, None))
+            torch.cuda.synchronize()
+            n_last = steps - (steps - 1) // nS * nS
+            got = [images[f % ring] for f in range(min(ring, steps))] if direct else [s_out[b] for b in range(n_last)]
+            for i, g in enumerate(got):
+                if not torch.equal(g.view(torch.int32), ref.view(torch.int32)):
+                    raise SystemExit(f"verify: strong-scaling leg, image {i} differs from the whole-frame render")
+            print(f"verify ok: strong-scaling leg, {len(got)} images bit-identical to a whole-frame render", file=sys.stderr)
+        strong = {"scaling": "strong", "value": WIDTH * HEIGHT * AA * AA * steps / s_dt, "unit": "path samples/s",
+                  "steps": steps, "frames_per_step": 1, "ms_per_step": s_dt / steps * 1e3, "frames_per_launch": nS,
+                  "region_ms": [x * 1e3 for x in s_sorted], "reported": "median region (max over ranks per region)",
+                  "parallelism": f"every frame's row tiles ({args.tile_rows} rows) dealt round-robin over {N} GPUs; "
+                                 + ("pixels stored in place in rank 0's images by every rank's kernel" if direct else
+                                    "one gather per launch (" + ("RCCL" if args.dist_backend == "nccl" else "gloo, host-staged")
+                                    + ") + rt_unpack_parts on rank 0")}
+        s_buf = s_gath = s_out = None
+
+    # --------------------------------------------------------------------------------------------------------------
     # the drop-in call and the single resident frame (wall time of rt_fire_all_rays incl. H2D and D2H,
     # median of >= 5 after 1 warm-up) -- one GPU, headline config
     # --------------------------------------------------------------------------------------------------------------
     call = None
     gpu_frame = None
-    if N == 1 and c3 and not args.no_call_timing:
+    if not D and c3 and not args.no_call_timing:
         import numpy as np
         host = np.zeros((HEIGHT, WIDTH, 3), dtype=np.float32)
         wall, kern = [], []
@@ -663,7 +777,8 @@ def main():
         # of those rays, the children of a mirror hit that took the answer of the sibling traced before them (the same ray)
         # instead of running the shape tests again: algorithmic work the reference does and this kernel proves redundant
         executed = (my_rays_per_frame - my_shared_per_frame) * frames_per_launch * fpr / (launch_ms * 1e-3) / 1e12
-        profiled = N == 1 and headline and onepass
+        profiled = not D and headline and onepass
+        traffic_frame, traffic_src = profiled_traffic_c3() if profiled else (None, None)
         n_nodes, n_unb = C.c_uint32(), C.c_uint32()
         lib.rt_scene_hierarchy_info(dev.handle, C.byref(n_nodes), C.byref(n_unb))
         if n_nodes.value:
@@ -671,7 +786,7 @@ def main():
             # figure is claimed here (RUSTRACER_NO_BVH=1 runs the credited linear scan; DESIGN.md §4 has both)
             achieved = None
             executed = None
-        if N == 1:
+        if not D:
             par = "1 GPU, whole frames"
         elif direct:
             par = ((f"weak: a step is {N} frames; every frame in {N} contiguous row blocks, frame f's block (rank + f) % {N} on `rank`"
@@ -684,12 +799,12 @@ def main():
                                   if p2p else "RCCL gather per launch, blocks placed by rank 0"))
         else:
             par = (f"strong: row tiles ({args.tile_rows} rows) of every frame round-robin over {N} GPUs, "
-                   + ("peer-copy gather (HIP IPC)" if (N > 1 and remote is not None) else "RCCL gather") + " to rank 0, rt_unpack_parts")
+                   + ("peer-copy gather (HIP IPC)" if (D and remote is not None) else "RCCL gather") + " to rank 0, rt_unpack_parts")
         out = {
             "metric": "path samples/sec (node) demo.yml pathtracer 1080p" if c3 else f"path samples/sec (node) {args.config}",
             "value": value, "unit": "path samples/s", "n_gpus": N, "steps": steps,
             "warmup": warmup, "ms_per_step": dt / steps * 1e3, "higher_is_better": True,
-            "scaling": "weak" if (weak or N == 1) else "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "scaling": "weak" if (weak or not D) else "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"{label}, pathtracer n={NUM_OF_RAYS} d={MAX_DEPTH} rr={RR_LIMIT}, {WIDTH}x{HEIGHT}, aa={AA}, "
                                    f"seeds {INIT_STATE}/{INIT_SEQ}",
                        "baseline_config": args.config, "parallelism": par, "frames_per_step": fpstep,
@@ -699,8 +814,8 @@ def main():
                        "timed_regions": repeats, "region_ms": [x * 1e3 for x in region_s], "reported": "median region"},
             "roofline": {"bound": "valu", "achieved": achieved, "peak": PEAK_FP32_VECTOR_TFLOPS, "unit": "TFLOP/s",
                          "frac": achieved / PEAK_FP32_VECTOR_TFLOPS if achieved is not None else None,
-                         "traffic": TRAFFIC_BYTES_PER_FRAME_C3 * frames_per_launch if profiled else None,
-                         "traffic_source": TRAFFIC_SOURCE if profiled else None,
+                         "traffic": traffic_frame * frames_per_launch if (profiled and traffic_frame) else None,
+                         "traffic_source": (traffic_src + " (1 GPU, c3, one-pass launches)") if (profiled and traffic_frame) else None,
                          "kernel": "k_pass", "launch_ms": launch_ms, "launch_latency_ms": latency_ms,
                          "rays_per_launch": my_rays_per_frame * frames_per_launch, "flops_per_ray": fpr,
                          "rays_shared_per_launch": my_shared_per_frame * frames_per_launch,
@@ -715,9 +830,11 @@ def main():
                          "note": "the reference's semantics forbid FMA contraction: 40 % of the 157.3 spec peak (62.9) is above "
                                  "the measured ceiling of unfused mul+add streams (61.6)"},
         }
+        if strong:
+            out["strong"] = strong
         if call:
             out["call"] = call
-        if N == 1 and not args.no_cpu_baseline and c3:
+        if not D and not args.no_cpu_baseline and c3:
             out["cpu_baseline"], outl = cpu_baseline(flat, cam, rr, WIDTH, HEIGHT, AA, gpu_frame)
             if outl:
                 out["outlier_fraction_vs_libm"] = outl["fraction"]
@@ -726,7 +843,7 @@ def main():
         os.dup2(real_stdout, 1)
         print(json.dumps(out), flush=True)
         os.dup2(2, 1)
-    if N > 1:
+    if D:
         images = None
         torch.cuda.synchronize()
         dist.barrier(group=cpu_group)       # consumers let go of rank 0's buffers before rank 0 frees them

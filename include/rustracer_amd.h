@@ -133,7 +133,8 @@ typedef struct rt_stats {
     double kernel_ms;     /* device time of the render kernels of this call (HIP events) */
     double total_ms;      /* host wall time of the call */
     uint64_t rays_shared; /* of `rays`: children of a mirror hit that took the answer of the sibling traced before them
-                             (the same ray, src/material.rs:225-246) without running the shape tests again; counted in
+                             (the same ray, src/material.rs:225-246) without running the shape tests again -- in scenes
+                             traced through the hierarchy: without the traversal, only the winner's own test; counted in
                              `rays`, `sphere_tests` and `plane_tests` as the reference counts them */
 } rt_stats;
 
@@ -201,7 +202,9 @@ int rt_render_frames(const rt_scene* scene, const rt_camera* cameras, uint32_t n
  * that every GPU the library runs on holds until the process ends (its address is resolved per device by rt_init,
  * or by the first call on a device).  Always one pass, one lane per pixel; no stats.  max_depth beyond what the
  * scratch holds for one 256-lane block (RT_NOALLOC_MAX_DEPTH) is rejected with an error.  Calls on one GPU share
- * that GPU's array: calls that overlap on one GPU (different streams) race; calls on one stream are ordered. */
+ * that GPU's array: calls that overlap on one GPU (different streams) race, undetected; calls on one stream are ordered.
+ * Under stream capture the device must have been visited before (rt_init(device) or an uncaptured call): resolving
+ * the array's address is not a capturable operation, and a first use under capture is refused with an error. */
 #define RT_NOALLOC_SCRATCH_BYTES (8u * 1024u * 1024u + 4096u)
 #define RT_NOALLOC_MAX_DEPTH 513u
 int rt_render_noalloc(const rt_scene* scene, const rt_camera* camera, const rt_renderer* renderer,
@@ -219,16 +222,25 @@ int rt_unpack_parts(const float* d_parts_rgb, uint64_t part_stride_pixels, uint3
  * HdrImage::set_pixels (src/imagetracer.rs:40, :105-125; src/hdrimage.rs:86-96).
  * out_rgb: width*height*3 floats, HdrImage order (row 0 = top), fully overwritten.
  * Multi-GPU fan-out is internal: the rows are dealt round-robin over the GPUs in use (RUSTRACER_DEVICES = a list of
- * device indices, or RUSTRACER_NUM_DEVICES = a count; default: one GPU per 2^21 samples of the frame, the current device first), every
- * GPU renders its part and copies it to the host over its own link, host threads place the rows in out_rgb.
- * Between calls the library keeps, per GPU, the uploaded World (reused while the tables' contents are unchanged),
- * the device image and a pinned staging buffer.  stats->kernel_ms is the longest GPU's. */
+ * device indices, or RUSTRACER_NUM_DEVICES = a count; default: one GPU per 2^21 samples of the frame, the current device
+ * first -- only the current device when the process is one rank of a multi-process job, WORLD_SIZE > 1 or LOCAL_RANK set),
+ * every GPU renders its part and copies it to the host over its own link, host threads place the rows in out_rgb.
+ * Between calls the library keeps, per GPU, the uploaded World, a pinned staging buffer (and, for the renderers that
+ * copy back, a device image), a stream and its events until rt_fire_release().  The World is reused when its tables
+ * are unchanged: a 128-bit content key over shapes, materials and texels selects it, the shape and material tables
+ * are then compared byte for byte; texels are trusted to the key (a colliding texel change is the one unverified case).
+ * stats->kernel_ms is the longest GPU's. */
 int rt_fire_all_rays(const rt_shape* shapes, uint32_t n_shapes,
                      const rt_material* materials, uint32_t n_materials,
                      const rt_texture* textures, uint32_t n_textures,
                      const rt_camera* camera, const rt_renderer* renderer,
                      uint32_t width, uint32_t height, uint64_t init_state, uint64_t init_seq,
                      uint32_t antialiasing_level, float* out_rgb, rt_stats* stats /* nullable */);
+
+/* Frees what rt_fire_all_rays keeps between calls on every GPU it has used: the uploaded World, the device image,
+ * the pinned staging buffer, the stream and its events (about 400 MB per GPU after an 8K frame).  The next
+ * rt_fire_all_rays builds them again.  No counterpart in the reference (its ImageTracer owns nothing but the image). */
+void rt_fire_release(void);
 
 /* Which GPUs the last rt_fire_all_rays of this thread used and how long each one's render kernels ran (the
  * fan-out is internal to that call; no counterpart in the reference, where rayon spreads the pixels over the cores,

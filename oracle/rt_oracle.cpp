@@ -528,16 +528,21 @@ extern "C" {
 // master PCG over every earlier pixel, as the reference's single stream requires); out_rgb holds
 // (row_end-row_begin)*width*3 floats.  Pixels are handed to n_threads workers from an atomic
 // counter (rayon par_iter stand-in; order-preserving like collect()).
-int oracle_fire_all_rays(const rt_shape* shapes, uint32_t n_shapes, const rt_material* materials,
-                         uint32_t n_materials, const rt_texture* textures, uint32_t n_textures,
-                         const rt_camera* camera, const rt_renderer* renderer, uint32_t width,
-                         uint32_t height, uint64_t init_state, uint64_t init_seq,
-                         uint32_t antialiasing_level, uint32_t row_begin, uint32_t row_end,
-                         int math_mode, int n_threads, float* out_rgb, rt_stats* stats) {
+// Columns [col_begin, col_end) of those rows only (a window of a frame too large to shade whole on the CPU: 10 002 shapes at
+// 7680x4320); out_rgb holds (row_end-row_begin)*(col_end-col_begin)*3 floats.  The master PCG still walks every pixel.
+int oracle_fire_all_rays_window(const rt_shape* shapes, uint32_t n_shapes, const rt_material* materials,
+                                uint32_t n_materials, const rt_texture* textures, uint32_t n_textures,
+                                const rt_camera* camera, const rt_renderer* renderer, uint32_t width,
+                                uint32_t height, uint64_t init_state, uint64_t init_seq,
+                                uint32_t antialiasing_level, uint32_t row_begin, uint32_t row_end,
+                                uint32_t col_begin, uint32_t col_end,
+                                int math_mode, int n_threads, float* out_rgb, rt_stats* stats) {
     World world;
     if (!build_world(&world, shapes, n_shapes, materials, n_materials, textures, n_textures, math_mode)) return 1;
     if (row_end > height) row_end = height;
     if (row_begin > row_end) row_begin = row_end;
+    if (col_end > width) col_end = width;
+    if (col_begin > col_end) col_begin = col_end;
     const auto t0 = std::chrono::steady_clock::now();
     Renderer r{&world, *renderer};
     ImageTracer tracer{width, height, make_camera(camera)};
@@ -546,8 +551,8 @@ int oracle_fire_all_rays(const rt_shape* shapes, uint32_t n_shapes, const rt_mat
     // all_rays (imagetracer.rs:61-84)
     std::vector<Rays> all_rays;
     std::vector<Ray> ray_store;
-    all_rays.reserve((size_t)(row_end - row_begin) * width);
-    ray_store.reserve((size_t)(row_end - row_begin) * width * aa * aa);
+    all_rays.reserve((size_t)(row_end - row_begin) * (col_end - col_begin));
+    ray_store.reserve((size_t)(row_end - row_begin) * (col_end - col_begin) * aa * aa);
     Pcg pcg(init_state, init_seq);
     for (uint32_t row = 0; row < row_end; ++row) {
         for (uint32_t col = 0; col < width; ++col) {
@@ -556,11 +561,11 @@ int oracle_fire_all_rays(const rt_shape* shapes, uint32_t n_shapes, const rt_mat
                 for (uint32_t sub_col = 0; sub_col < aa; ++sub_col) {
                     const float u_pixel = ((float)sub_row + pcg.random_float()) / (float)aa;
                     const float v_pixel = ((float)sub_col + pcg.random_float()) / (float)aa;
-                    if (row >= row_begin) ray_store.push_back(tracer.fire_ray(col, row, u_pixel, v_pixel));
+                    if (row >= row_begin && col >= col_begin && col < col_end) ray_store.push_back(tracer.fire_ray(col, row, u_pixel, v_pixel));
                 }
             }
             const uint64_t seq = (uint64_t)pcg.random();
-            if (row >= row_begin) all_rays.push_back({seq, first});
+            if (row >= row_begin && col >= col_begin && col < col_end) all_rays.push_back({seq, first});
         }
     }
 
@@ -573,7 +578,10 @@ int oracle_fire_all_rays(const rt_shape* shapes, uint32_t n_shapes, const rt_mat
     std::vector<Counters> counters(n_threads);
     auto worker = [&](int tid) {
         Counters cnt;
-        const size_t grain = 64;
+        // pixels per hand-out: 64, fewer when the call shades only a small window (every thread should get several)
+        size_t grain = n_pixels / (8 * (size_t)n_threads);
+        if (grain > 64) grain = 64;
+        if (grain < 1) grain = 1;
         for (;;) {
             const size_t b = next.fetch_add(grain);
             if (b >= n_pixels) break;
@@ -615,6 +623,17 @@ int oracle_fire_all_rays(const rt_shape* shapes, uint32_t n_shapes, const rt_mat
         stats->total_ms = std::chrono::duration<double, std::milli>(t2 - t0).count();   // incl. all_rays
     }
     return 0;
+}
+
+int oracle_fire_all_rays(const rt_shape* shapes, uint32_t n_shapes, const rt_material* materials,
+                         uint32_t n_materials, const rt_texture* textures, uint32_t n_textures,
+                         const rt_camera* camera, const rt_renderer* renderer, uint32_t width,
+                         uint32_t height, uint64_t init_state, uint64_t init_seq,
+                         uint32_t antialiasing_level, uint32_t row_begin, uint32_t row_end,
+                         int math_mode, int n_threads, float* out_rgb, rt_stats* stats) {
+    return oracle_fire_all_rays_window(shapes, n_shapes, materials, n_materials, textures, n_textures, camera, renderer, width,
+                                       height, init_state, init_seq, antialiasing_level, row_begin, row_end, 0u, width,
+                                       math_mode, n_threads, out_rgb, stats);
 }
 
 // Diagnostics: per-pixel ray counts of subsequent oracle_fire_all_rays calls (NULL = off).

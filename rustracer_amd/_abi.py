@@ -103,6 +103,7 @@ SIGNATURES = {
                                    P(rt_texture), C.c_uint32, P(rt_camera), P(rt_renderer),
                                    C.c_uint32, C.c_uint32, C.c_uint64, C.c_uint64, C.c_uint32,
                                    P(C.c_float), P(rt_stats)]),
+    "rt_fire_release": (None, []),
     "rt_last_fire_devices": (C.c_uint32, [P(C.c_int32), P(C.c_double), C.c_uint32]),
     "rt_world_ray_intersection": (C.c_int, [C.c_void_p, P(rt_ray), C.c_uint64, P(rt_hit)]),
     "rt_renderer_solve": (C.c_int, [C.c_void_p, P(rt_renderer), P(rt_ray), P(rt_pcg), C.c_uint64,

@@ -29,6 +29,10 @@ def lib():
         h.oracle_fire_all_rays.argtypes = scene + [P(_abi.rt_camera), P(_abi.rt_renderer), C.c_uint32, C.c_uint32,
                                                    C.c_uint64, C.c_uint64, C.c_uint32, C.c_uint32, C.c_uint32,
                                                    C.c_int, C.c_int, P(C.c_float), P(_abi.rt_stats)]
+        h.oracle_fire_all_rays_window.argtypes = scene + [P(_abi.rt_camera), P(_abi.rt_renderer), C.c_uint32, C.c_uint32,
+                                                          C.c_uint64, C.c_uint64, C.c_uint32, C.c_uint32, C.c_uint32,
+                                                          C.c_uint32, C.c_uint32, C.c_int, C.c_int, P(C.c_float),
+                                                          P(_abi.rt_stats)]
         h.oracle_all_rays_seeds.argtypes = [C.c_uint32, C.c_uint32, C.c_uint64, C.c_uint64, C.c_uint32,
                                             P(C.c_float), P(C.c_uint64)]
         h.oracle_fire_ray.argtypes = [P(_abi.rt_camera), C.c_uint32, C.c_uint32, P(C.c_uint32), P(C.c_uint32),
@@ -47,7 +51,7 @@ def lib():
         h.oracle_create_onb_from_z.argtypes = [P(C.c_float), P(C.c_float)]
         h.oracle_transform.argtypes = [P(C.c_float), P(C.c_float), C.c_int, P(C.c_float), P(C.c_float)]
         h.oracle_math_eval.argtypes = [C.c_int, C.c_int, P(C.c_float), P(C.c_float), C.c_uint64, P(C.c_float)]
-        for name in ("oracle_fire_all_rays", "oracle_all_rays_seeds", "oracle_fire_ray", "oracle_camera_fire_ray",
+        for name in ("oracle_fire_all_rays", "oracle_fire_all_rays_window", "oracle_all_rays_seeds", "oracle_fire_ray", "oracle_camera_fire_ray",
                      "oracle_world_ray_intersection", "oracle_renderer_solve", "oracle_pcg_new", "oracle_pcg_random",
                      "oracle_pcg_random_float", "oracle_pigment_get_color", "oracle_scatter_ray",
                      "oracle_create_onb_from_z", "oracle_transform", "oracle_math_eval"):
@@ -80,13 +84,15 @@ class OraclePcg:
 
 
 def fire_all_rays(flat, cam, rr, width, height, init_state=42, init_seq=54, aa=1, rows=None,
-                  math_mode=MATH_STRICT, n_threads=8):
-    """oracle ImageTracer::fire_all_rays -> (image (rows, w, 3) float32, stats dict)."""
+                  math_mode=MATH_STRICT, n_threads=8, cols=None):
+    """oracle ImageTracer::fire_all_rays -> (image (rows, cols, 3) float32, stats dict); `rows` / `cols`: the half-open
+    window of the frame that is shaded (default: the whole frame)."""
     r0, r1 = (0, height) if rows is None else rows
-    out = np.zeros((max(r1 - r0, 0), width, 3), dtype=np.float32)
+    c0, c1 = (0, width) if cols is None else cols
+    out = np.zeros((max(r1 - r0, 0), max(c1 - c0, 0), 3), dtype=np.float32)
     st = _abi.rt_stats()
-    rc = lib().oracle_fire_all_rays(*flat.args(), C.byref(cam), C.byref(rr), width, height, init_state, init_seq,
-                                    aa, r0, r1, math_mode, n_threads, fptr(out), C.byref(st))
+    rc = lib().oracle_fire_all_rays_window(*flat.args(), C.byref(cam), C.byref(rr), width, height, init_state, init_seq,
+                                           aa, r0, r1, c0, c1, math_mode, n_threads, fptr(out), C.byref(st))
     assert rc == 0
     return out, st.as_dict()
 

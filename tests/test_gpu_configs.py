@@ -2,9 +2,10 @@
 and the internal multi-GPU fan-out of the drop-in call.
 
 C2 runs at its full size.  C4 / C5 use the configs' renderer parameters (pathtracer n=10, depth 3, roulette 3;
-C5 with 4x4 antialiasing) at the largest resolution the CPU oracle -- a literal linear scan over 228 / 10 002
-shapes per ray -- finishes in about a minute on the GPU box's 16 host threads.  Bar: bit-exact against the
-strict-math oracle, every counter equal.
+C5 with 4x4 antialiasing) twice: whole frames at the largest resolution the CPU oracle -- a literal linear scan over
+228 / 10 002 shapes per ray -- finishes in about a minute on the GPU box's 16 host threads, and at their FULL quoted
+sizes (3840x2160; 7680x4320 x 16 spp) with whole rows / 64-pixel windows of the frame checked against the oracle plus
+the whole-frame-equals-its-parts property.  Bar: bit-exact against the strict-math oracle, every counter equal.
 """
 import ctypes as C
 import os
@@ -69,6 +70,87 @@ def test_c5_random_spheres_aa4_at_the_configs_renderer_parameters():
         assert gs[k] == rs[k], (k, gs[k], rs[k])
 
 
+def whole_frame_and_parts(world, cam, rr, w, h, aa, n_parts, whole_schedule, parts_schedule):
+    """One frame twice on the GPU: whole in one launch, and as n_parts row-tile parts (1-row tiles dealt round-robin)
+    assembled by rt_unpack_parts.  Returns (whole image on the device, its stats, assembled image, summed part stats)."""
+    import torch
+    lib = _abi.lib()
+    c, r = flatten_camera(cam), rr.flatten()
+    dev = world.device()
+    whole, ws = gpu_render(world, cam, rr, w, h, aa=aa, schedule=whole_schedule)
+    dev.set_schedule(parts_schedule)
+    sizes = [lib.rt_partition_pixels(w, h, C.byref(_abi.rt_partition(p, n_parts, 1, 0))) for p in range(n_parts)]
+    assert sum(sizes) == w * h
+    stride = max(sizes)
+    parts = torch.zeros((n_parts, stride, 3), dtype=torch.float32, device="cuda")
+    tot = {k: 0 for k in COUNTERS}
+    for p in range(n_parts):
+        part = _abi.rt_partition(p, n_parts, 1, 0)
+        st = _abi.rt_stats()
+        _abi.check(lib.rt_render(dev.handle, C.byref(c), C.byref(r), w, h, 42, 54, aa, C.byref(part), parts[p].data_ptr(),
+                                 None, C.byref(st)))
+        print(f"  part {p}/{n_parts}: {st.kernel_ms:.0f} ms, {st.rays} rays", flush=True)
+        for k in COUNTERS:
+            tot[k] += getattr(st, k)
+    dev.set_schedule(())
+    image = torch.zeros((h, w, 3), dtype=torch.float32, device="cuda")
+    _abi.check(lib.rt_unpack_parts(parts.data_ptr(), stride, n_parts, 1, w, h, image.data_ptr(), None))
+    torch.cuda.synchronize()
+    del parts
+    return whole, ws, image, tot
+
+
+def test_c4_flake_full_size_3840x2160_rows_against_the_oracle():
+    """BASELINE config 4 at its quoted size: the textured sphere-flake (228 shapes, checkered + image pigments), pathtracer
+    n=10 d=3 rr=3, 3840x2160.  The oracle's literal linear scan cannot shade 8.3 M pixels in the suite's time, but it takes
+    a row range: four whole rows spread over the frame (the serial master stream walked up to each row, src/imagetracer.rs:
+    61-84; src/world.rs:32-50 over 228 shapes) are compared bit for bit with the same rows of the full-size GPU frame.
+    Size-independent property on top: the whole frame in one launch == the frame as 8 row-tile parts under the other
+    schedule, every counter equal, every pixel finite."""
+    import torch
+    w, h = 3840, 2160
+    world = flake_world(True)
+    cam, rr = flake_camera(w, h), ra.PathTracer(world, ra.BLACK, 10, 3, 3)
+    whole, ws, image, tot = whole_frame_and_parts(world, cam, rr, w, h, 1, 8, (0,), ())
+    assert torch.equal(whole.view(torch.int32), image.view(torch.int32)), "C4 full size: parts differ from the whole frame"
+    for k in COUNTERS:
+        assert tot[k] == ws[k], (k, tot[k], ws[k])
+    assert bool(torch.isfinite(whole).all())
+    assert ws["samples"] == w * h
+    print(f"C4 full size: {ws['rays']} rays, kernel {ws['kernel_ms']:.0f} ms")
+    flat, c, r = flatten_world(world), flatten_camera(cam), rr.flatten()
+    for row in (0, 641, 1378, 2159):
+        ref, rs = O.fire_all_rays(flat, c, r, w, h, 42, 54, 1, rows=(row, row + 1), n_threads=THREADS)
+        assert_bit_equal(whole[row:row + 1].cpu().numpy(), ref, f"C4 3840x2160 row {row}")
+        assert rs["samples"] == w
+
+
+def test_c5_random_spheres_full_size_7680x4320_16spp_windows_against_the_oracle():
+    """BASELINE config 5 at its quoted size: 10 002 shapes, 7680x4320, 16 samples per pixel, pathtracer n=10 d=3 rr=3 (1.03e11
+    rays through the exact-winner hierarchy).  Against the oracle (literal scan of all 10 002 shapes per ray): 64-pixel
+    windows spread over the frame -- top (sky), the horizon band, the spheres, the bottom-right corner -- bit for bit.
+    Size-independent property: whole frame (one launch) == 8 row-tile parts (short-pass schedule) assembled by
+    rt_unpack_parts, counters equal, all finite."""
+    import torch
+    w, h, aa = 7680, 4320, 4
+    world = random_spheres_world(10000)
+    cam, rr = random_spheres_camera(w, h), ra.PathTracer(world, ra.BLACK, 10, 3, 3)
+    whole, ws, image, tot = whole_frame_and_parts(world, cam, rr, w, h, aa, 8, (0,), ())
+    assert torch.equal(whole.view(torch.int32), image.view(torch.int32)), "C5 full size: parts differ from the whole frame"
+    del image
+    for k in COUNTERS:
+        assert tot[k] == ws[k], (k, tot[k], ws[k])
+    assert bool(torch.isfinite(whole).all())
+    assert ws["samples"] == w * h * aa * aa
+    print(f"C5 full size: {ws['rays']} rays, kernel {ws['kernel_ms']:.0f} ms")
+    flat, c, r = flatten_world(world), flatten_camera(cam), rr.flatten()
+    for row, col in ((0, 0), (1900, 3808), (2477, 1111), (3200, 6000), (4319, 7616)):
+        ref, rs = O.fire_all_rays(flat, c, r, w, h, 42, 54, aa, rows=(row, row + 1), cols=(col, col + 64), n_threads=THREADS)
+        assert_bit_equal(whole[row:row + 1, col:col + 64].cpu().numpy(), ref, f"C5 7680x4320x16spp window ({row}, {col})")
+        assert rs["samples"] == 64 * aa * aa and rs["rays"] > 0
+        print(f"  window ({row}, {col}): oracle {rs['rays']} rays", flush=True)
+
+
 def libm_outliers(gpu_img, libm_img):
     """Pixels whose radiance differs from the libm-mode oracle by more than 1e-4 relative (north_star's tolerance)."""
     g, o = np.asarray(gpu_img, dtype=np.float64), np.asarray(libm_img, dtype=np.float64)
@@ -122,6 +204,22 @@ def test_fire_all_rays_fans_out_over_the_listed_devices(monkeypatch):
         assert_bit_equal(g, o, "fan-out after a scene change")
         assert gs["rays"] == os_["rays"]
     monkeypatch.delenv("RUSTRACER_DEVICES")
+    # rt_fire_release lets go of every cached context; the next call builds them again and renders the same frame
+    lib.rt_fire_release()
+    lib.rt_fire_release()
+    g, gs = gpu_image(world, cam, rr, w, h)
+    assert_bit_equal(g, ref, "after rt_fire_release")
+    assert gs["rays"] == rs["rays"]
+    # a World that differs from the cached one in a single material colour must not be served from the cache
+    world2 = demo_world()
+    flat2 = flatten_world(world2)
+    flat2.materials[0].emitted.c1[0] = 0.25
+    c2, r2 = flatten_camera(cam), rr.flatten()
+    out2 = np.zeros((h, w, 3), dtype=np.float32)
+    _abi.check(lib.rt_fire_all_rays(*flat2.args(), C.byref(c2), C.byref(r2), w, h, 42, 54, 1, O.fptr(out2), None))
+    ref2, _ = O.fire_all_rays(flat2, c2, r2, w, h, 42, 54, 1, n_threads=THREADS)
+    assert_bit_equal(out2, ref2, "fan-out cache after a one-colour change")
+    assert not np.array_equal(out2, ref)
     monkeypatch.setenv("RUSTRACER_NUM_DEVICES", "7")       # more devices than the box has
     out = np.zeros((4, 4, 3), dtype=np.float32)
     st = _abi.rt_stats()

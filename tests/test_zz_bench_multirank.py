@@ -44,6 +44,31 @@ def test_two_ranks_on_one_gpu_assemble_bit_identical_frames(scaling, gather):
     assert len(lines) == 1, r.stdout[:2000]      # exactly one JSON line on stdout, whatever the process groups print
     line = json.loads(lines[0])
     assert line["n_gpus"] == 2 and line["scaling"] == scaling
+    if scaling == "weak":
+        # the weak line carries the strong definition too (the same frames split by row tiles), verified as well
+        assert line["strong"]["scaling"] == "strong" and line["strong"]["value"] > 0
+        assert "verify ok: strong-scaling leg" in r.stderr, r.stderr[-2000:]
+
+
+@pytest.mark.parametrize("scaling", ["weak", "strong"])
+def test_rccl_gather_executes_with_one_rank_through_the_n_rank_path(scaling):
+    """What one GPU can execute of the RCCL transport (the reference's seam: src/imagetracer.rs:112-124, pixels collected
+    into one HdrImage): `--force-dist` runs bench.py's N-rank code path with world size 1 under torch.distributed.run --
+    the nccl (= RCCL) process group initialises, dist.gather moves the parts between device buffers, rank 0 places the
+    blocks / rt_unpack_parts assembles the tiles, and --verify compares every image with a whole-frame render."""
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "3", "--warmup", "1",
+           "--repeats", "1", "--force-dist", "--dist-backend", "nccl", "--gather", "rccl", "--scaling", scaling, "--verify"]
+    r = subprocess.run(cmd, cwd=ROOT, capture_output=True, text=True, timeout=280)
+    assert r.returncode == 0, r.stderr[-2000:]
+    assert "verify ok" in r.stderr, r.stderr[-2000:]
+    lines = r.stdout.strip().splitlines()
+    assert len(lines) == 1, r.stdout[:2000]
+    line = json.loads(lines[0])
+    assert line["n_gpus"] == 1
+    assert "RCCL gather" in line["config"]["parallelism"], line["config"]["parallelism"]
+    if scaling == "weak":
+        assert "RCCL" in line["strong"]["parallelism"] and "verify ok: strong-scaling leg" in r.stderr
 
 
 def test_direct_stores_fall_back_to_copies_when_the_probe_fails():
