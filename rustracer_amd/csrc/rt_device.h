@@ -355,59 +355,95 @@ struct DBvh {
     uint32_t by_octant;          // 1: `nodes` holds the 8 layouts; 0: one layout (small trees: 8 copies would only thrash the L1)
 };
 
+// The traversal of one ray as a resumable state (per lane), so that a kernel may keep rays IN FLIGHT across its rounds:
+// a wave's rays need very different numbers of node visits (incoherent bounce rays: 16 of 64 lanes were active per
+// traversal instruction when every round waited for its slowest ray), so the throughput body lets the lanes whose
+// traversal has finished go on to shading and to their next ray while the others keep walking (bvh_advance's min_done).
+struct BvhTrav {
+    uint32_t i, i_end;        // next node of this ray's layout and the layout's end (i >= i_end: finished)
+    int best;                 // winner so far (-1 none) and its record, as the linear scan keeps them
+    float best_t;
+    Vec3 best_o, best_d;
+    uint32_t best_kind;
+};
+
+// one shape's own test; the winner is the minimum by (t, index).  `diag` is wave-uniform.
 template <bool AFFINE>
-__device__ __forceinline__ int bvh_closest_hit(const DBvh B, const DScan* __restrict__ scan, const DWRows* __restrict__ wrows,
-                                               uint32_t n_shapes, Vec3 ro, Vec3 rd, float tmin, float tmax,
-                                               float& best_t, Vec3& best_o, Vec3& best_d, uint32_t& best_kind,
-                                               const bool diag = false /* wave-uniform: sparse form allowed (diag_ray_ok) */,
-                                               const int cached = -2 /* per lane: -2 unknown; else the known answer to this very query
-                                                                        (-1 no hit, >= 0 the winning shape): only that shape is tested */) {
+__device__ __forceinline__ void bvh_test_shape(const DScan* __restrict__ scan, const DWRows* __restrict__ wrows, uint32_t i,
+                                               Vec3 ro, Vec3 rd, float tmin, float tmax, bool diag, BvhTrav& T) {
+    const Rows3 R = load_rows(scan[i].inv);
+    const uint32_t kind = scan[i].kind;
+    Vec3 o, d;
+    if (AFFINE && diag) {
+        o = rows_point_diag(R, ro.x, ro.y, ro.z);
+        d = rows_vector_diag(R, rd.x, rd.y, rd.z);
+    } else {
+        o = rows_point<AFFINE>(R, AFFINE ? nullptr : wrows[i].inv_w, ro.x, ro.y, ro.z);
+        d = rows_vector(R, rd.x, rd.y, rd.z);
+    }
+    float t = 0.0f;
+    bool hit;
+    if (kind == RT_SHAPE_SPHERE) hit = sphere_t_nb(o, d, tmin, tmax, t);
+    else hit = plane_t_nb(o, d, tmin, tmax, t);
+    if (hit && (T.best < 0 || t < T.best_t || (t == T.best_t && (int)i < T.best))) {
+        T.best = (int)i;
+        T.best_t = t;
+        T.best_o = o;
+        T.best_d = d;
+        T.best_kind = kind;
+    }
+}
+
+// Start a ray (every ACTIVE lane starts one; call it inside the branch of the starting lanes): the unbounded shapes,
+// the fall-backs to the linear scan, the entry node.  diag: wave-uniform over the starting lanes (sparse form allowed,
+// diag_ray_ok).  cached, per lane: -2 unknown; else the known answer to this very query (-1 no hit, >= 0 the winning
+// shape): only that shape is tested (the children of a mirror hit all trace the same ray, src/material.rs:225-246;
+// the same inputs through the same arithmetic give the same t and object-space ray).
+template <bool AFFINE>
+__device__ __forceinline__ void bvh_begin(const DBvh B, const DScan* __restrict__ scan, const DWRows* __restrict__ wrows,
+                                          uint32_t n_shapes, Vec3 ro, Vec3 rd, float tmin, float tmax, const bool diag,
+                                          const int cached, BvhTrav& T) {
+    T.i = 0u;
+    T.i_end = 0u;
     const bool finite = (__builtin_fabsf(ro.x) < __builtin_inff()) && (__builtin_fabsf(ro.y) < __builtin_inff()) &&
                         (__builtin_fabsf(ro.z) < __builtin_inff()) && (__builtin_fabsf(rd.x) < __builtin_inff()) &&
                         (__builtin_fabsf(rd.y) < __builtin_inff()) && (__builtin_fabsf(rd.z) < __builtin_inff());
-    if (__ballot(!finite) != 0ull)
-        return scan_closest_hit_g<AFFINE, 2>(scan, wrows, n_shapes, ro, rd, tmin, tmax, best_t, best_o, best_d, best_kind);
-    int best = -1;
-    best_t = 0.0f;
-    best_kind = 0u;
-    best_o = {0.f, 0.f, 0.f};
-    best_d = {0.f, 0.f, 0.f};
-    // one shape's own test; the winner is the minimum by (t, index)
-    auto test_shape = [&](uint32_t i) {
-        const Rows3 R = load_rows(scan[i].inv);
-        const uint32_t kind = scan[i].kind;
-        Vec3 o, d;
-        if (AFFINE && diag) {
-            o = rows_point_diag(R, ro.x, ro.y, ro.z);
-            d = rows_vector_diag(R, rd.x, rd.y, rd.z);
-        } else {
-            o = rows_point<AFFINE>(R, AFFINE ? nullptr : wrows[i].inv_w, ro.x, ro.y, ro.z);
-            d = rows_vector(R, rd.x, rd.y, rd.z);
-        }
-        float t = 0.0f;
-        bool hit;
-        if (kind == RT_SHAPE_SPHERE) hit = sphere_t_nb(o, d, tmin, tmax, t);
-        else hit = plane_t_nb(o, d, tmin, tmax, t);
-        if (hit && (best < 0 || t < best_t || (t == best_t && (int)i < best))) {
-            best = (int)i;
-            best_t = t;
-            best_o = o;
-            best_d = d;
-            best_kind = kind;
-        }
-    };
-    // A lane that already knows the winner of this exact ray (the children of a mirror hit all trace the same ray,
-    // src/material.rs:225-246) skips the unbounded shapes and the traversal and re-runs the winner's own test at the end:
-    // the same inputs through the same arithmetic give the same t and object-space ray.
+    if (__ballot(!finite) != 0ull) {
+        T.best = scan_closest_hit_g<AFFINE, 2>(scan, wrows, n_shapes, ro, rd, tmin, tmax, T.best_t, T.best_o, T.best_d, T.best_kind);
+        return;
+    }
+    T.best = -1;
+    T.best_t = 0.0f;
+    T.best_kind = 0u;
+    T.best_o = {0.f, 0.f, 0.f};
+    T.best_d = {0.f, 0.f, 0.f};
     const bool walk = (cached == -2);
     for (uint32_t u = 0; u < B.n_unbounded; ++u)
-        if (walk) test_shape(B.unbounded[u]);
+        if (walk) bvh_test_shape<AFFINE>(scan, wrows, B.unbounded[u], ro, rd, tmin, tmax, diag, T);
     // Plane::ray_intersection reports a hit whose t is NaN (its two rejections are comparisons that NaN fails,
     // src/shape.rs:198-204); the linear scan then keeps that hit iff no earlier shape is hit at all, which is not
     // a minimum over (t, index).  Only unbounded shapes can do this: such a wave takes the linear scan.
-    if (__ballot(best >= 0 && best_t != best_t) != 0ull)
-        return scan_closest_hit_g<AFFINE, 2>(scan, wrows, n_shapes, ro, rd, tmin, tmax, best_t, best_o, best_d, best_kind);
+    if (__ballot(T.best >= 0 && T.best_t != T.best_t) != 0ull) {
+        T.best = scan_closest_hit_g<AFFINE, 2>(scan, wrows, n_shapes, ro, rd, tmin, tmax, T.best_t, T.best_o, T.best_d, T.best_kind);
+        return;
+    }
+    // this ray's near-to-far layout: nodes [i, i_end) of the concatenated array
+    const uint32_t octant = B.by_octant ? ((rd.x < 0.0f ? 1u : 0u) | (rd.y < 0.0f ? 2u : 0u) | (rd.z < 0.0f ? 4u : 0u)) : 0u;
+    T.i_end = (octant + 1u) * B.n_nodes;
+    T.i = walk ? octant * B.n_nodes : T.i_end;
+    if (cached >= 0) bvh_test_shape<AFFINE>(scan, wrows, (uint32_t)cached, ro, rd, tmin, tmax, diag, T);
+}
 
+// Walk the rays in flight (`act`: this lane has one; ro / rd / tmin / tmax / T are its ray and state) until at least
+// min_done of them have finished or none has work left.  "while-while" traversal: every lane walks inner nodes until it
+// stands on a leaf whose box it passes (or is done), then the wave runs the shape tests of all those leaves together -- a
+// lane's leaf visits are few, so the expensive tests execute a few times per ray instead of once per node step of the
+// slowest lane.  lane_diag: this lane's ray admits the sparse form (diag_ray_ok; only read if scene_diag).
+template <bool AFFINE>
+__device__ __forceinline__ void bvh_advance(const DBvh B, const DScan* __restrict__ scan, const DWRows* __restrict__ wrows,
+                                            Vec3 ro, Vec3 rd, float tmin, float tmax, const bool scene_diag, const bool lane_diag,
+                                            const bool act, const uint32_t min_done, BvhTrav& T) {
+    if (__ballot(act && T.i < T.i_end) == 0ull) return;
     const float EPS = 5.9604645e-8f;
     const float big = 1.0e30f;
     const float idx = (__builtin_fabsf(rd.x) < 1.0e-30f) ? __builtin_copysignf(big, rd.x) : 1.0f / rd.x;
@@ -415,14 +451,12 @@ __device__ __forceinline__ int bvh_closest_hit(const DBvh B, const DScan* __rest
     const float idz = (__builtin_fabsf(rd.z) < 1.0e-30f) ? __builtin_copysignf(big, rd.z) : 1.0f / rd.z;
     const float o2 = ro.x * ro.x + ro.y * ro.y + ro.z * ro.z;
     const float o1 = __builtin_fabsf(ro.x) + __builtin_fabsf(ro.y) + __builtin_fabsf(ro.z);
-    // "while-while" traversal: every lane walks inner nodes until it stands on a leaf whose box it passes (or is
-    // done), then the wave runs the shape tests of all those leaves together -- a lane's leaf visits are few, so
-    // the expensive tests execute a few times per ray instead of once per node step of the slowest lane.
-    const uint32_t octant = B.by_octant ? ((rd.x < 0.0f ? 1u : 0u) | (rd.y < 0.0f ? 2u : 0u) | (rd.z < 0.0f ? 4u : 0u)) : 0u;
-    const uint32_t i_end = (octant + 1u) * B.n_nodes;
-    uint32_t i = walk ? octant * B.n_nodes : i_end;  // this ray's near-to-far layout: nodes [i, i_end) of the concatenated array
     for (;;) {
       uint32_t leaf_first = 0, leaf_count = 0;
+      uint32_t i = T.i;
+      const uint32_t i_end = act ? T.i_end : 0u;
+      const int best = T.best;
+      const float best_t = T.best_t;
       while (i < i_end) {
         // the conservative node test is this library's own arithmetic, not the reference's: fused multiply-adds are welcome
         // (every bound below carries a relative margin far above one rounding)
@@ -465,11 +499,30 @@ __device__ __forceinline__ int bvh_closest_hit(const DBvh B, const DScan* __rest
             i = skip;
         }
       }
-      if (__ballot(leaf_count != 0u) == 0ull) break;
-      for (uint32_t k = 0; k < leaf_count; ++k) test_shape(B.leaf_shapes[leaf_first + k]);
+      if (act) T.i = i;
+      const unsigned long long at_leaf = __ballot(leaf_count != 0u);
+      if (at_leaf == 0ull) break;
+      const bool diag = AFFINE && scene_diag && __ballot(leaf_count != 0u && !lane_diag) == 0ull;
+      for (uint32_t k = 0; k < leaf_count; ++k) bvh_test_shape<AFFINE>(scan, wrows, B.leaf_shapes[leaf_first + k], ro, rd, tmin, tmax, diag, T);
+      if ((uint32_t)__popcll(__ballot(act && T.i >= T.i_end)) >= min_done) break;
     }
-    if (cached >= 0) test_shape((uint32_t)cached);
-    return best;
+}
+
+// World::ray_intersection through the hierarchy in one call (every active lane traces one ray to the end).
+template <bool AFFINE>
+__device__ __forceinline__ int bvh_closest_hit(const DBvh B, const DScan* __restrict__ scan, const DWRows* __restrict__ wrows,
+                                               uint32_t n_shapes, Vec3 ro, Vec3 rd, float tmin, float tmax,
+                                               float& best_t, Vec3& best_o, Vec3& best_d, uint32_t& best_kind,
+                                               const bool diag = false /* wave-uniform: sparse form allowed (diag_ray_ok) */,
+                                               const int cached = -2 /* per lane, see bvh_begin */) {
+    BvhTrav T;
+    bvh_begin<AFFINE>(B, scan, wrows, n_shapes, ro, rd, tmin, tmax, diag, cached, T);
+    bvh_advance<AFFINE>(B, scan, wrows, ro, rd, tmin, tmax, diag, true, true, 65u, T);
+    best_t = T.best_t;
+    best_o = T.best_o;
+    best_d = T.best_d;
+    best_kind = T.best_kind;
+    return T.best;
 }
 
 // HitRecord fields of the winner (src/shape.rs:134-142, :205-213) on the split layout.  want_geom

@@ -124,6 +124,8 @@ struct PassParams {
     uint32_t budget;                 // rounds a path may run in this pass before it is parked (0: no limit)
     uint32_t lanes_target;           // team size = lanes_target / queue length (power of two, <= max_team)
     uint32_t max_team;
+    uint32_t trav_min_done;          // FAST over a hierarchy: a round's traversal ends once this many of the wave's rays have returned
+                                     // (0: every round waits for all of them)
     uint32_t idle_div;               // refill once 1/idle_div of a wave's teams are idle
     uint32_t backlog;                // queue entries per team slot of the grid (>= 1): fewer, fuller waves
     PassCtl* ctl;
@@ -226,8 +228,30 @@ __device__ __forceinline__ void local_to_global(ColdParams P, uint32_t item, uin
     grow = (tile * P->n_parts + part) * tile_rows + (lrow - tile * tile_rows);
 }
 
-// ImageTracer::fire_ray + Camera::fire_ray for sample `samp` of pixel (grow, gcol)
-// (imagetracer.rs:52-56, :67-75; camera.rs:68-75, :132-143); advances the master PCG by two draws.
+// ImageTracer::fire_ray + Camera::fire_ray for the point (u_pixel, v_pixel) of pixel (grow, gcol)
+// (imagetracer.rs:52-56; camera.rs:68-75, :132-143)
+template <bool AFFINE>
+__device__ __forceinline__ void camera_ray(ColdParams P, const FrameEntry* __restrict__ F, uint32_t grow, uint32_t gcol,
+                                           float u_pixel, float v_pixel, Vec3& ro, Vec3& rd) {
+    const float u = ((float)gcol + u_pixel) / (float)P->width;
+    const float v = 1.0f - ((float)grow + v_pixel) / (float)P->height;
+    const float dist = F->cam_distance, aspect = F->cam_aspect;
+    float cox, coy, coz, cdx, cdy, cdz;
+    if (F->cam_kind == RT_CAMERA_ORTHOGONAL) {
+        cox = -1.0f; coy = (1.0f - 2.0f * u) * aspect; coz = 2.0f * v - 1.0f;
+        cdx = 1.0f; cdy = 0.0f; cdz = 0.0f;
+    } else {
+        cox = -dist; coy = 0.0f; coz = 0.0f;
+        cdx = dist; cdy = (1.0f - 2.0f * u) * aspect; cdz = 2.0f * v - 1.0f;
+    }
+    float M[16];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) M[i] = F->cam_m[i];
+    ro = xform_point<AFFINE>(M, cox, coy, coz);
+    rd = xform_vector(M, cdx, cdy, cdz);
+}
+
+// the ray of sample `samp` of pixel (grow, gcol) (imagetracer.rs:67-75); advances the master PCG by two draws.
 template <bool AFFINE>
 __device__ __forceinline__ void primary_ray(ColdParams P, const FrameEntry* __restrict__ F, uint32_t grow, uint32_t gcol,
                                             uint32_t samp, uint64_t& mstate, Vec3& ro, Vec3& rd) {
@@ -245,22 +269,7 @@ __device__ __forceinline__ void primary_ray(ColdParams P, const FrameEntry* __re
         u_pixel = ((float)sub_row + rf0) / (float)aa;
         v_pixel = ((float)sub_col + rf1) / (float)aa;
     }
-    const float u = ((float)gcol + u_pixel) / (float)P->width;
-    const float v = 1.0f - ((float)grow + v_pixel) / (float)P->height;
-    const float dist = F->cam_distance, aspect = F->cam_aspect;
-    float cox, coy, coz, cdx, cdy, cdz;
-    if (F->cam_kind == RT_CAMERA_ORTHOGONAL) {
-        cox = -1.0f; coy = (1.0f - 2.0f * u) * aspect; coz = 2.0f * v - 1.0f;
-        cdx = 1.0f; cdy = 0.0f; cdz = 0.0f;
-    } else {
-        cox = -dist; coy = 0.0f; coz = 0.0f;
-        cdx = dist; cdy = (1.0f - 2.0f * u) * aspect; cdz = 2.0f * v - 1.0f;
-    }
-    float M[16];
-#pragma unroll
-    for (int i = 0; i < 16; ++i) M[i] = F->cam_m[i];
-    ro = xform_point<AFFINE>(M, cox, coy, coz);
-    rd = xform_vector(M, cdx, cdy, cdz);
+    camera_ray<AFFINE>(P, F, grow, gcol, u_pixel, v_pixel, ro, rd);
 }
 
 // Lane (within its team) of last-level candidate (sibling j, s earlier survivors): rows of the
@@ -356,7 +365,7 @@ __global__ __launch_bounds__(RT_BLOCK, RT_WAVES_PER_EU) void k_pass(const PassPa
     extern __shared__ float4 lds_raw[];
     // FAST >= 2: the throughput body with drain helpers once the queue is dry; FAST == 3: mixed hand-outs too, for launches short
     // enough that their end matters more than the steady state (a frame or a few)
-    constexpr bool HELP_K = (FAST >= 2) && (RT_DRAIN_HELPERS != 0);
+    constexpr bool HELP_K = (FAST == 2 || FAST == 3) && (RT_DRAIN_HELPERS != 0);
     const uint32_t tid = threadIdx.x;
     const uint32_t lane = tid & 63u;
     const uint32_t gtid = blockIdx.x * RT_BLOCK + tid;
@@ -498,6 +507,16 @@ __global__ __launch_bounds__(RT_BLOCK, RT_WAVES_PER_EU) void k_pass(const PassPa
     // counters (kept by the team leader)
     uint32_t n_rays = 0, n_samples = 0, n_diffuse = 0, n_specular = 0;
     uint32_t u_rays = 0, u_samples = 0, u_diffuse = 0, u_specular = 0, u_shared = 0;   // FAST: the same, wave-uniform (ballot counts)
+    // FAST over a hierarchy: the lane's ray may stay in flight over several rounds (bvh_begin / bvh_advance, rt_device.h)
+    constexpr bool INFL_C = FAST == 4;
+    static_assert(!INFL_C || !SCENE_LDS, "rays in flight are for scenes traced through the hierarchy");
+    const bool infl = INFL_C && P.bvh.n_nodes != 0u && P.trav_min_done != 0u;
+    const uint32_t trav_min_done = P.trav_min_done;
+    BvhTrav tr;
+    tr.i = 0u; tr.i_end = 0u; tr.best = -1; tr.best_t = 0.f; tr.best_kind = 0u;
+    tr.best_o = {0.f, 0.f, 0.f}; tr.best_d = {0.f, 0.f, 0.f};
+    Vec3 tr_d = {0.f, 0.f, 0.f};       // direction of the ray in flight (its origin is cw)
+    bool tr_fly = false, tr_ok = false; // a ray is in flight / it admits the sparse closest-hit form
     uint32_t l_sibs = 0, l_extra = 0;   // FAST, per lane: mirror siblings resolved beside their first child / siblings taken from drain helpers
 
     // wave-private slice of the input queue

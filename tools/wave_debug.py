@@ -6,12 +6,19 @@ import torch
 import rustracer_amd as ra
 from rustracer_amd import _abi
 if os.environ.get("RT_LIB"): _abi.LIB_PATH = os.environ["RT_LIB"]
-from rustracer_amd.scenes import demo_camera, demo_world
+from rustracer_amd.scenes import demo_camera, demo_world, flake_camera, flake_world, random_spheres_camera, random_spheres_world
 from rustracer_amd.world import flatten_camera
 
 W, H = int(os.environ.get("RW", 1920)), int(os.environ.get("RH", 1080))
 AA = int(os.environ.get("RAA", 1))
-world = demo_world(); cam = flatten_camera(demo_camera(W, H)); rr = ra.PathTracer(world, ra.BLACK, 10, 3, 3).flatten()
+SCENE = os.environ.get("RSCENE", "demo")
+if SCENE == "c4":
+    world = flake_world(True); cam = flatten_camera(flake_camera(W, H))
+elif SCENE == "c5":
+    world = random_spheres_world(10000); cam = flatten_camera(random_spheres_camera(W, H))
+else:
+    world = demo_world(); cam = flatten_camera(demo_camera(W, H))
+rr = ra.PathTracer(world, ra.BLACK, 10, 3, 3).flatten()
 NF = int(os.environ.get("RFRAMES", 1))
 dev = world.device(); img = torch.zeros((NF, H, W, 3), device="cuda")
 cams = (_abi.rt_camera * NF)(*([cam] * NF)); outs = (C.c_void_p * NF)(*[img[b].data_ptr() for b in range(NF)])
@@ -19,7 +26,8 @@ lib = _abi.lib()
 path = "/tmp/waves.bin"
 os.environ["RUSTRACER_DEBUG_WAVES"] = path
 os.environ["RUSTRACER_DEBUG_PASSES"] = "1"
-for rep in range(3):
+if os.environ.get("RONEPASS"): dev.set_schedule((0,))
+for rep in range(int(os.environ.get("RREPS", 3))):
     st = _abi.rt_stats()
     _abi.check(lib.rt_render_frames(dev.handle, cams, NF, C.byref(rr), W, H, 42, 54, AA, None, outs, None, C.byref(st)))
 raw = np.fromfile(path, dtype=np.uint64)
