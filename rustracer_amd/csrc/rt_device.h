@@ -611,11 +611,7 @@ __device__ __forceinline__ Vec3 diffuse_scatter_dir(float rf0, float rf1, Vec3 n
     const float sin_theta = sqrt_rn_normal(1.0f - rf0);
     const float phi = 6.2831854820251465f * rf1;  // (2.0 * PI) * pcg.1
     float sn, cs;
-#if defined(RT_ABLATE) && RT_ABLATE == 2         // cost probe (wrong pixels): hardware sin / cos instead of the binary64 kernels
-    sn = __builtin_amdgcn_sinf(rf1); cs = __builtin_amdgcn_cosf(rf1);
-#else
     rt_sincosf(phi, &sn, &cs);
-#endif
     Vec3 d;
     d.x = e1x * cs * cos_theta + e2x * sn * cos_theta + n.x * sin_theta;
     d.y = e1y * cs * cos_theta + e2y * sn * cos_theta + n.y * sin_theta;

@@ -1194,6 +1194,8 @@ __global__ __launch_bounds__(RT_BLOCK, RT_WAVES_PER_EU) void k_pass(const PassPa
             // and siblings taken from drain helpers (a ray, a diffuse scatter)
 #pragma unroll
             for (int off = 32; off > 0; off >>= 1) { l_sibs += __shfl_down(l_sibs, off); l_extra += __shfl_down(l_extra, off); }
+            // rays traced round by round: one level-0 ray per sample, the rest children of a diffuse or of a mirror hit
+            u_specular += u_rays - u_samples - u_diffuse;
             u_rays += l_sibs + l_extra;
             u_specular += l_sibs;
             u_shared += l_sibs;
