@@ -270,8 +270,9 @@ int rt_brdf_scatter_ray(uint32_t brdf, const float* rf, const float* incoming_di
 
 /* Evaluate include/rt_strict_math.h on the GPU (fn: 0 sin, 1 cos, 2 atan2(y=a,x=b), 3 acos,
  * 4 a/b, 5 sqrt(a) as the render kernels compute it, 6 its short form for a == 0 or a >= 2^-96,
- * 7 rt_maxf of a and b, 8 the bits of rt_f32_to_u32_sat of a);
- * used to prove host/device bit-equality of the shared math. */
+ * 7 rt_maxf of a and b, 8 the bits of rt_f32_to_u32_sat of a); used to prove host/device bit-equality of the shared math.
+ * fn 9 / 10: the render kernels' single-precision ESTIMATES of atan2(a, b) / acos(a) that pre-select pigment cells
+ * (never a pixel value: csrc/rt_device.h, hit_pigments); the tests hold them to their stated error bounds. */
 int rt_strict_math_eval(int fn, const float* a, const float* b, uint64_t n, float* out);
 
 #ifdef __cplusplus

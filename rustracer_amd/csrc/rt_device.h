@@ -598,6 +598,117 @@ __device__ __forceinline__ Vec3 pigment_color(const DPigment* __restrict__ p, co
 }
 
 // ---------------------------------------------------------------------------------------------
+// Pigments of a hit: the colours of the brdf pigment and of the emitted radiance at the hit's (u, v)
+// (src/shape.rs:101-108, :187-192; src/material.rs:54-70, :86-96).
+//
+// A pigment never reads (u, v) itself, only the CELL it falls in: floor(u * steps) and floor(v * steps) of a checkered
+// pigment, the texel (u * w) as u32, (v * h) as u32 of an image.  On a sphere (u, v) = (atan2(y, x) / 2 pi, acos(z) / pi)
+// costs four binary64 divides, a binary64 square root and two polynomials (rt_strict_math.h) -- 30 % of the textured
+// sphere-flake's frame.  So the cell is first looked for with single-precision estimates of u and v whose distance from
+// the reference's f32 values is bounded (RT_UV_DELTA_*); if no cell boundary lies within that bound of the scaled
+// estimate, the reference's value falls in the same cell and the colour is the reference's, bit for bit.  Lanes for
+// which a boundary is that close, or anything is not finite, or the hit is near a pole, evaluate the reference
+// functions as before (a wave-level rarity: 0.1-0.5 % of the lanes per coordinate).  The bounds are checked against the
+// strict functions on the GPU (tests/test_gpu_parity.py: rt_strict_math_eval fn 9, 10).
+// ---------------------------------------------------------------------------------------------
+#define RT_UV_DELTA_ATAN 1.5e-6f   // |atan2_est - rt_atan2f| <= this (radians); measured maximum 2.4e-7
+#define RT_UV_DELTA_U 6.0e-7f      // |u_est - u_reference|: DELTA_ATAN / 2 pi, the reference's divide and wrap, this multiply
+#define RT_UV_DELTA_V 8.0e-7f      // |v_est - v_reference|: (DELTA_ATAN + the square root's 2.4e-7) / pi, the divide, the multiply
+
+// atan2 for finite operands, not both zero: octant reduction, a * P(a^2) with P of degree 7 (|a P - atan a| < 4e-8 in
+// exact arithmetic, < 1.5e-7 evaluated in f32), v_rcp_f32 for the ratio (1 ulp).  NaN when y == x == 0 or an operand is not finite.
+__device__ __forceinline__ float atan2_est(float y, float x) {
+    const float ax = __builtin_fabsf(x), ay = __builtin_fabsf(y);
+    const float mx = __builtin_fmaxf(ax, ay), mn = __builtin_fminf(ax, ay);
+    const float a = mn * __builtin_amdgcn_rcpf(mx);
+    const float z = a * a;
+    float p = -0.004053469747304916f;
+    p = p * z + 0.021858856081962585f;
+    p = p * z + -0.055906206369400024f;
+    p = p * z + 0.09641734510660172f;
+    p = p * z + -0.13908442854881287f;
+    p = p * z + 0.19946527481079102f;
+    p = p * z + -0.33329856395721436f;
+    p = p * z + 0.9999993443489075f;
+    float r = a * p;
+    if (ay > ax) r = 1.5707963705062866f - r;
+    if (x < 0.0f) r = 3.1415927410125732f - r;
+    return (y < 0.0f) ? -r : r;
+}
+// acos for |z| < 1 the same way the reference defines it: atan2(sqrt((1 - z)(1 + z)), z); NaN beyond
+__device__ __forceinline__ float acos_est(float z) {
+    return atan2_est(__builtin_amdgcn_sqrtf((1.0f - z) * (1.0f + z)), z);    // v_sqrt_f32: 1 ulp
+}
+// the cell floor(c * scale) if it is certain: c_est within delta of the reference's c, the reference rounds c * scale once
+__device__ __forceinline__ bool cell_sure(float c_est, float delta, float scale, uint32_t& cell) {
+    const float x = c_est * scale;
+    const float eps = delta * scale + x * 2.4e-7f + 1.0e-30f;
+    const float lo = __builtin_floorf(x - eps), hi = __builtin_floorf(x + eps);
+    cell = (uint32_t)hi;                                   // only used when sure (then 0 <= hi < 2^31)
+    return (lo == hi) && (x - eps > 0.0f) && (hi < 2147483648.0f);   // a NaN fails every comparison
+}
+// Pigment::get_color from certain cells; false if this pigment needs the reference's (u, v)
+__device__ __forceinline__ bool pigment_color_est(const DPigment* __restrict__ p, const float* __restrict__ texels, float u_est, float v_est, Vec3& c) {
+    const uint32_t kind = p->kind;
+    c = {p->c1[0], p->c1[1], p->c1[2]};
+    if (kind == RT_PIGMENT_CHECKERED) {
+        const float steps = (float)p->steps;
+        uint32_t iu, iv;
+        const bool ok_u = cell_sure(u_est, RT_UV_DELTA_U, steps, iu), ok_v = cell_sure(v_est, RT_UV_DELTA_V, steps, iv);
+        const bool ok = ok_u && ok_v;
+        if (ok && (iu % 2u) != (iv % 2u)) c = {p->c2[0], p->c2[1], p->c2[2]};
+        return ok;
+    }
+    if (kind == RT_PIGMENT_IMAGE) {
+        const uint32_t w = p->tex_w, h = p->tex_h;
+        uint32_t col, row;
+        const bool ok_u = cell_sure(u_est, RT_UV_DELTA_U, (float)w, col), ok_v = cell_sure(v_est, RT_UV_DELTA_V, (float)h, row);
+        const bool ok = ok_u && ok_v;
+        if (ok) {
+            if (col >= w) col = w - 1;
+            if (row >= h) row = h - 1;
+            const float* px = texels + p->tex_off + 3ull * ((uint64_t)row * w + col);
+            c = {px[0], px[1], px[2]};
+        }
+        return ok;
+    }
+    return true;
+}
+// hit_color = brdf pigment, emitted = emitted pigment at the hit (render.rs:146-147); flags bit 1 / bit 2: that pigment
+// reads (u, v); (hx, hy, hz): the hit point in object space (inv_ray.at(t)); hc / em come in holding the uniform colours
+__device__ __forceinline__ void hit_pigments(const DMaterial* __restrict__ M, const float* __restrict__ texels, uint32_t sflags,
+                                             bool sphere, float hx, float hy, float hz, Vec3& hc, Vec3& em) {
+    if (!sphere) {
+        const float u = hx - __builtin_floorf(hx), v = hy - __builtin_floorf(hy);     // shape.rs:187-192
+        if (sflags & 2u) hc = pigment_color(&M->brdf_pigment, texels, u, v);
+        if (sflags & 4u) em = pigment_color(&M->emitted, texels, u, v);
+        return;
+    }
+    bool need_b = (sflags & 2u) != 0u, need_e = (sflags & 4u) != 0u;
+#ifndef RT_NO_UV_ESTIMATE
+    {
+        float u_est = atan2_est(hy, hx) * 0.15915494309189535f;       // / 2 pi
+        if (u_est < 0.0f) u_est += 1.0f;
+        // a u within the bound of the wrap at 0 could be the reference's u + 1; a hit within 1e-6 of a pole, or off the unit
+        // sphere (|z| > 1: the reference's acos is NaN there), is left to the reference functions
+        const bool tame = (__builtin_fabsf(u_est) > 2.0f * RT_UV_DELTA_U) && (__builtin_fabsf(hz) < 0.999999f);
+        const float v_est = acos_est(hz) * 0.3183098861837907f;       // / pi
+        Vec3 c;
+        if (need_b && tame && pigment_color_est(&M->brdf_pigment, texels, u_est, v_est, c)) { hc = c; need_b = false; }
+        if (need_e && tame && pigment_color_est(&M->emitted, texels, u_est, v_est, c)) { em = c; need_e = false; }
+    }
+    if (__ballot(need_b || need_e) == 0ull) return;
+#endif
+    if (need_b || need_e) {
+        float u = rt_atan2f(hy, hx) / 6.2831854820251465f;  // 2.0 * PI in f32 (shape.rs:101-108)
+        const float v = rt_acosf(hz) / 3.1415927410125732f; // PI in f32
+        if (u < 0.0f) u += 1.0f;
+        if (need_b) hc = pigment_color(&M->brdf_pigment, texels, u, v);
+        if (need_e) em = pigment_color(&M->emitted, texels, u, v);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
 // BRDF::scatter_ray (src/material.rs:161-186, :225-246) + create_onb_from_z (src/normal.rs:143-158)
 // ---------------------------------------------------------------------------------------------
 __device__ __forceinline__ Vec3 diffuse_scatter_dir(float rf0, float rf1, Vec3 n) {

@@ -608,21 +608,8 @@ __global__ __launch_bounds__(RT_BLOCK, RT_WAVES_PER_EU) void k_pass(const PassPa
         const bool can_open = (K_ALGO == RT_ALGO_PATHTRACER) && (depth + 1u <= P.max_depth);
         const float hx = lo.x + ld.x * t, hy = lo.y + ld.y * t, hz = lo.z + ld.z * t;   // inv_ray.at(t)
         const bool sphere = (bkind == RT_SHAPE_SPHERE);
-        if (sflags & 6u) {
-            // some pigment of this material reads (u, v)
-            float u, v;
-            if (sphere) {
-                u = rt_atan2f(hy, hx) / 6.2831854820251465f;  // 2.0 * PI in f32
-                v = rt_acosf(hz) / 3.1415927410125732f;       // PI in f32
-                if (u < 0.0f) u += 1.0f;
-            } else {
-                u = hx - __builtin_floorf(hx);
-                v = hy - __builtin_floorf(hy);
-            }
-            const DMaterial* M = mats + (SCENE_LDS ? (uint32_t)best : scan[best].material);
-            if (sflags & 2u) hc = pigment_color(&M->brdf_pigment, texels, u, v);
-            if (sflags & 4u) em = pigment_color(&M->emitted, texels, u, v);
-        }
+        if (sflags & 6u)   // some pigment of this material reads (u, v)
+            hit_pigments(mats + (SCENE_LDS ? (uint32_t)best : scan[best].material), texels, sflags, sphere, hx, hy, hz, hc, em);
         RT_DBG_MARK(6);
         if (K_ALGO == RT_ALGO_FLAT) {
             R.vr = em.x + hc.x; R.vg = em.y + hc.y; R.vb = em.z + hc.z;   // render.rs:83-84
@@ -1322,18 +1309,7 @@ __global__ __launch_bounds__(RT_BLOCK) void k_simple(const PassParams P, const D
                 const uint32_t sflags = __float_as_uint(sh0.w);
                 if (sflags & 6u) {
                     const float hx = lo.x + ld.x * t, hy = lo.y + ld.y * t, hz = lo.z + ld.z * t;   // inv_ray.at(t)
-                    float u, v;
-                    if (bkind == RT_SHAPE_SPHERE) {
-                        u = rt_atan2f(hy, hx) / 6.2831854820251465f;
-                        v = rt_acosf(hz) / 3.1415927410125732f;
-                        if (u < 0.0f) u += 1.0f;
-                    } else {
-                        u = hx - __builtin_floorf(hx);
-                        v = hy - __builtin_floorf(hy);
-                    }
-                    const DMaterial* M = mats + (SCENE_LDS ? (uint32_t)best : g_scan[best].material);
-                    if (sflags & 2u) hc = pigment_color(&M->brdf_pigment, texels, u, v);
-                    if (sflags & 4u) em = pigment_color(&M->emitted, texels, u, v);
+                    hit_pigments(mats + (SCENE_LDS ? (uint32_t)best : g_scan[best].material), texels, sflags, bkind == RT_SHAPE_SPHERE, hx, hy, hz, hc, em);
                 }
                 vr = em.x + hc.x; vg = em.y + hc.y; vb = em.z + hc.z;   // render.rs:83-84
             }
@@ -1414,6 +1390,8 @@ __global__ __launch_bounds__(RT_BLOCK) void k_math(int fn, const float* __restri
         case 6: r = sqrt_rn_normal(a[i]); break;          // its short form: 0, or >= 2^-96
         case 7: r = rt_maxf(a[i], b[i]); break;           // Rust f32::max (render.rs:148, :150)
         case 8: r = __uint_as_float(rt_f32_to_u32_sat(a[i])); break;   // Rust `as u32`, the result's bits (material.rs:56-57, :88-89)
+        case 9: r = atan2_est(a[i], b[i]); break;         // the single-precision estimates behind the pigment cells (rt_device.h)
+        case 10: r = acos_est(a[i]); break;
         default: r = __builtin_sqrtf(a[i]); break;
     }
     out[i] = r;

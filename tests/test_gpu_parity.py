@@ -124,6 +124,40 @@ def test_strict_math_host_device_bit_equal():
         assert_bit_equal(_gpu_math(6, (np.float32(1.0) - rf).astype(np.float32)), O.math_eval(5, (np.float32(1.0) - rf).astype(np.float32)), "sqrt(1 - rf)")
 
 
+def test_pigment_cell_estimates_stay_within_their_bounds():
+    """A pigment reads only the CELL (u, v) falls in (src/material.rs:54-70, :86-96), so the kernels first look for it with
+    single-precision estimates of atan2 / acos and evaluate the reference functions only where a cell boundary lies within
+    the estimates' error bound (csrc/rt_device.h: hit_pigments).  That is exact as long as the bounds hold: here the
+    estimates are compared with the strict functions on 2^22 points each (random directions at every scale, axis-aligned
+    and near-axis points, the whole range of z up to the poles' cut-off)."""
+    rng = np.random.default_rng(5)
+    n = 1 << 22
+    y = rng.normal(size=n).astype(np.float32) * np.float32(10.0) ** rng.integers(-6, 7, n).astype(np.float32)
+    x = rng.normal(size=n).astype(np.float32) * np.float32(10.0) ** rng.integers(-6, 7, n).astype(np.float32)
+    k = n // 8
+    y[:k] *= np.float32(1e-6)                                   # near the x axis (both signs of x: the wrap at u = 0 / 1)
+    x[k:2 * k] *= np.float32(1e-6)                              # near the y axis
+    y[2 * k:3 * k] = x[2 * k:3 * k] * (1 + rng.normal(size=k).astype(np.float32) * np.float32(1e-6))   # near the octant boundary
+    est = _gpu_math(9, y, x)
+    ref = _gpu_math(2, y, x)
+    d_atan = float(np.abs(est.astype(np.float64) - ref.astype(np.float64)).max())
+    z = np.concatenate([rng.uniform(-0.999999, 0.999999, n - 4096), np.linspace(-0.999999, 0.999999, 4096)]).astype(np.float32)
+    z = z[np.abs(z) < np.float32(0.999999)]
+    d_acos = float(np.abs(_gpu_math(10, z).astype(np.float64) - _gpu_math(3, z).astype(np.float64)).max())
+    # u and v as the kernels form them, against the reference's f32 values (shape.rs:101-108)
+    u_est = est * np.float32(0.15915494309189535)
+    u_est = np.where(u_est < 0, u_est + np.float32(1.0), u_est).astype(np.float32)
+    u_ref = (ref / np.float32(6.2831854820251465)).astype(np.float32)
+    u_ref = np.where(u_ref < 0, u_ref + np.float32(1.0), u_ref).astype(np.float32)
+    away = np.abs(u_est) > 2 * 6.0e-7                           # the kernels leave the wrap at 0 to the reference functions
+    d_u = float(np.abs(u_est.astype(np.float64) - u_ref.astype(np.float64))[away].max())
+    v_est = _gpu_math(10, z) * np.float32(0.3183098861837907)
+    v_ref = (_gpu_math(3, z) / np.float32(3.1415927410125732)).astype(np.float32)
+    d_v = float(np.abs(v_est.astype(np.float64) - v_ref.astype(np.float64)).max())
+    print(f"estimate errors: atan2 {d_atan:.3e} (bound 1.5e-6), acos {d_acos:.3e}, u {d_u:.3e} (bound 6e-7), v {d_v:.3e} (bound 8e-7)")
+    assert d_atan <= 1.0e-6 and d_acos <= 1.5e-6 and d_u <= 4.5e-7 and d_v <= 6.0e-7
+
+
 def test_shared_header_helpers_against_an_independent_statement_of_rusts_semantics():
     """rt_maxf and rt_f32_to_u32_sat live in the header the oracle shares with the kernels, so a bit-exact image test
     cannot see a bug in them; here the device versions are checked against numpy's own statement of Rust's f32::max
