@@ -503,11 +503,14 @@ __global__ __launch_bounds__(RT_BLOCK, RT_WAVES_PER_EU) void k_pass(const PassPa
     uint32_t c_hit = 0;
     // ... and a hit opened by such a repeated ray is its sibling's hit, so its own children repeat the sibling's children: per
     // lane, tmpl[l] (l = 1..4, one quad behind the saved levels) is what the level whose children are traced at level l had
-    // learned when it last closed -- valid for the next hit at that level iff that hit is opened by a repeated ray (the body
-    // voids the entry below a hit opened by a new ray).  A pure mirror chain then needs one traversal per level, not one per hit.
+    // learned when it last closed -- valid for the next hit at that level iff that hit is opened by a repeated ray and itself
+    // started from a template (the body voids the entry below every hit that starts knowing nothing, whichever ray opened it:
+    // a repeated ray whose siblings the roulette killed has no predecessor below).  A pure mirror chain then needs one
+    // traversal per level, not one per hit.  FAST lanes own their pixel to its end (K_BUDGET 0), so the entries are the lane's.
     bool ray_cached = false;
     const uint32_t tmpl_base = P.stack_slots * RT_NF;
     const bool mirror_cache = FAST && !SCENE_LDS && P.bvh.n_nodes != 0u && P.num_of_rays < 256u && P.n_shapes < 0x7FFFF0u;
+    if (mirror_cache) stack.st4(P.stack_slots, 0, make_float4(0.f, 0.f, 0.f, 0.f));   // nothing learned yet
     Vec3 cw = {0.f, 0.f, 0.f};           // hit.world_point
     Vec3 cv = {0.f, 0.f, 1.f};           // diffuse: hit.normal (raw); specular: the mirrored direction
     // counters (kept by the team leader)

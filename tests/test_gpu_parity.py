@@ -657,6 +657,34 @@ def test_hierarchy_scene_of_ellipsoids_mirrors_and_pigments_path_traced():
     check_image(world, cam, ra.PathTracer(world, ra.BLACK, 3, 2, 1), 96, 60, aa=2, init_state=5, init_seq=77)
 
 
+@pytest.mark.parametrize("n,d,rr_limit", [(2, 5, 0), (3, 4, 1), (2, 4, 2), (4, 3, 0)])
+def test_mirror_chains_over_a_hierarchy_with_the_roulette_at_every_level(n, d, rr_limit):
+    """Mirror templates (k_pass: a hit opened by a repeated ray inherits what its sibling's children learned): dark
+    mirrors, so that the roulette kills most first children, over a 200-sphere hierarchy -- a hit opened by a repeated
+    ray whose siblings all died starts from nothing and must void what the level below it had kept.  (The first
+    version of the rule voided only below hits opened by new rays and read a stale / never written entry here.)"""
+    rng = np.random.default_rng(101 + n)
+    world = ra.World()
+    world.add(ra.Sphere(ra.scaling((40, 40, 40)), ra.Material(ra.DiffuseBRDF(ra.UniformPigment(ra.BLACK)), ra.UniformPigment((0.9, 1.0, 0.8)))))
+    for k in range(200):
+        c = (float(rng.uniform(-3, 3)), float(rng.uniform(-3.5, 3.5)), float(rng.uniform(-2.5, 2.5)))
+        r = float(rng.uniform(0.5, 1.2))
+        lum = float(rng.choice([0.5, 0.8, 0.95, 0.99]))
+        col = (lum, lum * float(rng.uniform(0.2, 1.0)), lum * float(rng.uniform(0.2, 1.0)))
+        brdf = ra.SpecularBRDF(ra.UniformPigment(col)) if k % 10 != 0 else ra.DiffuseBRDF(ra.UniformPigment(col))
+        world.add(ra.Sphere(ra.translation(c) * ra.scaling((r, r, r)), ra.Material(brdf, ra.UniformPigment(ra.BLACK))))
+    cam = ra.PerspectiveCamera(1.0, 1.5, ra.translation((-6.0, 0.0, 0.0)))
+    w, h = 144, 96
+    rr = ra.PathTracer(world, ra.BLACK, n, d, rr_limit)
+    ref, rs = oracle_image(world, cam, rr, w, h, init_state=9 + d, init_seq=4 + n)
+    assert rs["specular_scatters"] > w * h, rs
+    for schedule in [(), (0,)]:
+        g, gs = gpu_render(world, cam, rr, w, h, schedule=schedule, init_state=9 + d, init_seq=4 + n)
+        assert_bit_equal(g.cpu().numpy(), ref, f"dark mirrors n={n} d={d} rr={rr_limit} schedule={schedule}")
+        for k in COUNTERS:
+            assert gs[k] == rs[k], (schedule, k)
+
+
 def test_random_scenes():
     """Random scenes (1-400 shapes: LDS and HBM tables, hierarchy, projective matrices, duplicates, every pigment and
     BRDF), cameras, renderers and seeds from tools/fuzz_parity.py, each also under a random pass schedule / team cap

@@ -279,6 +279,7 @@ def main():
     for seed in range(first, first + n):
         case = random_case(seed)
         t0 = time.perf_counter()
+        print(f"seed {seed}: ..   {describe(*case)}", flush=True)      # named before it runs: a fault on the card ends the process
         try:
             _, st = check_case(seed, case)
             check_batch(seed, case)
