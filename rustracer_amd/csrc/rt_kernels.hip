@@ -79,6 +79,18 @@ struct FrameEntry {
 };
 static_assert(sizeof(FrameEntry) == 96, "FrameEntry layout");
 
+// Experiment (profiles/r03_dropped_open_hit_mailbox.txt; off in the shipped library): the geometry of a hit that opens --
+// needed by one lane in eleven per round -- is posted to a workgroup mailbox in LDS and computed by ONE wave of the block
+// over the compacted list, instead of by every wave for its few lanes.  Two workgroup barriers per round.
+#ifndef RT_MAILBOX
+#define RT_MAILBOX 0
+#endif
+#define RT_MB_SLOTS 40u          // postings per round and block; lanes beyond compute their hit themselves
+#define RT_MB_FIELDS 16u         // in [0, 10): shape | flags, hit point (3), object-space direction (3), world direction (3);
+                                 // out [10, 16): world point (3), child direction / normal (3) -- an area of their own: a wave may post the
+                                 // next round's inputs while a slower one still reads this round's results
+#define RT_MB_BYTES (16u + RT_MB_FIELDS * RT_MB_SLOTS * 4u)
+
 #define RT_INLINE_FRAMES 8   // launches of up to this many frames carry their frame table in the kernarg
 
 // Everything a pass needs, passed by value (kernarg -> SGPRs).
@@ -467,6 +479,11 @@ __global__ __launch_bounds__(RT_BLOCK, RT_WAVES_PER_EU) void k_pass(const PassPa
             lds_tri[tid] = (uint8_t)tj;
         }
     }
+#if RT_MAILBOX
+    constexpr bool MB_K = SCENE_LDS && STACK_LDS && (FAST == 1 || FAST == 2 || FAST == 3);
+    volatile uint32_t* lds_mb = reinterpret_cast<volatile uint32_t*>(lds_stack + (size_t)P.stack_slots * (RT_NF / 4) * RT_BLOCK);
+    if (MB_K && tid < 4u) lds_mb[tid] = 0u;        // postings [2], live waves [2]: one of each per round parity
+#endif
     if (TEAMS || SCENE_LDS || FAST) __syncthreads();
     const DScan* __restrict__ scan = SCENE_LDS ? lds_scan : g_scan;
     const DMRows* __restrict__ mrows = SCENE_LDS ? lds_mrows : g_mrows;
@@ -526,6 +543,13 @@ __global__ __launch_bounds__(RT_BLOCK, RT_WAVES_PER_EU) void k_pass(const PassPa
     tr.best_o = {0.f, 0.f, 0.f}; tr.best_d = {0.f, 0.f, 0.f};
     Vec3 tr_d = {0.f, 0.f, 0.f};       // direction of the ray in flight (its origin is cw)
     bool tr_fly = false, tr_ok = false; // a ray is in flight / it admits the sparse closest-hit form
+#if RT_MAILBOX
+    bool wave_done = false;             // mailbox experiment: this wave has nothing left but keeps the block's barriers company
+    uint32_t mb_par = 0u;               // ... the round's parity
+    bool open_req = false;              // ... this lane's hit opens: cw / cv hold the hit point and the object-space direction until the exchange
+    uint32_t open_tag = 0u;             // ... shape | sphere << 30 | mirror << 31
+    uint32_t dbg_mb_round = 0u;         // ... the round's number (the executor rotates)
+#endif
     uint32_t l_sibs = 0, l_extra = 0;   // FAST, per lane: mirror siblings resolved beside their first child / siblings taken from drain helpers
 
     // wave-private slice of the input queue
@@ -575,6 +599,28 @@ __global__ __launch_bounds__(RT_BLOCK, RT_WAVES_PER_EU) void k_pass(const PassPa
         }
         return scan_closest_hit_g<AFFINE, RT_SCAN_GROUP>(scan, g_wrows, P.n_shapes, o, d, tmin, tmax, t, lo, ld, bkind);
     };
+
+#if RT_MAILBOX
+    // world_point and normal of a hit that opens and the direction its children take (src/shape.rs:88-95, :134-138, :175-182,
+    // :205-209; material.rs:225-246): the mailbox experiment's copy of the block in rt_fast_body.inc
+    auto open_geometry = [&](const uint32_t shape_, const bool sphere_, const bool mirror_, const float hx_, const float hy_, const float hz_,
+                             const Vec3 ld_, const Vec3 d_, Vec3& wp_, Vec3& ncv_) {
+        const Rows3 MW = load_rows(mrows[shape_].m);
+        const Rows3 IW = load_rows(scan[shape_].inv);
+        wp_ = rows_point<AFFINE>(MW, AFFINE ? nullptr : g_wrows[shape_].m_w, hx_, hy_, hz_);
+        float nx, ny, nz, dp;
+        if (sphere_) {
+            dp = hx_ * ld_.x + hy_ * ld_.y + hz_ * ld_.z;
+            nx = hx_; ny = hy_; nz = hz_;
+        } else {
+            dp = 0.0f * ld_.x + 0.0f * ld_.y + 1.0f * ld_.z;
+            nx = 0.0f; ny = 0.0f; nz = 1.0f;
+        }
+        if (!(dp < 0.0f)) { nx = -nx; ny = -ny; nz = -nz; }
+        const Vec3 nrm = rows_normal(IW, nx, ny, nz);
+        ncv_ = mirror_ ? specular_scatter_dir(d_, nrm) : nrm;
+    };
+#endif
 
     // ---------------------------------------------------------------------------------------------
     // one node: intersect + shade (render.rs:57-67, :76-89, :136-171)
@@ -893,6 +939,11 @@ __global__ __launch_bounds__(RT_BLOCK, RT_WAVES_PER_EU) void k_pass(const PassPa
                 busy = true;
             }
         }
+#if RT_MAILBOX
+        // every wave of the block meets the round's two barriers until all of them are done (the body's exchange ends the loop)
+        if (__ballot(busy) == 0ull && exhausted) wave_done = true;
+        if (!MB_K)
+#endif
         if (__ballot(busy) == 0ull) {
             if (exhausted) break;           // queue empty and every team retired or parked
             continue;                       // only skipped entries so far: take more
