@@ -337,13 +337,24 @@ __device__ __forceinline__ int scan_closest_hit_g(const DScan* __restrict__ scan
 // projective matrices are unbounded: they are tested for every ray.  Rays with a non-finite component, and rays
 // for which an unbounded shape reports a hit at t = NaN, take the linear scan (a NaN t wins or loses by order there).
 // ---------------------------------------------------------------------------------------------
+// What a node test needs is folded into the node on the host (rt_host.inc: BvhBuild::build), in double, rounded up.  With
+// D = |origin - farthest corner of the box|, c = that corner's distance from the world origin, W^2 = 2 |o|^2 + 2 c^2 and the
+// maxima below the node hmax, qa = 2 (12 kF + 17) rho2^2, qb = 2 * 16 rho2 rhoF, g0 = 2 eps (6 kF + 7):
+//     S = eps (qa D^2 + qb D W) + g0,      box growth  hmax (sqrt(1 + S) - 1) <= hmax min(S / 2, sqrt(S))
+// The node carries sa = eps qa / 2, sb = eps qb / 2, sg = g0 / 2 (each padded by 1e-5 for the roundings of their
+// evaluation and the v_sqrt_f32 estimate of D W) and 2 c^2; the traversal evaluates S / 2 = sa D^2 + sb sqrt(D^2 W^2) + sg.
+// Two shortcuts that were measured and do NOT work on the sphere-flake: bounding D W by (D^2 + W^2) / 2 inflates the boxes of
+// small shapes near the ray's origin (D << W), and dropping the sqrt(S) branch inflates them for rays that start on the sky
+// sphere (D ~ 100, S ~ 140 for the smallest spheres: growth 69 hmax instead of 12 hmax) -- 16x the frame time either way.
+// The slab arithmetic's own rounding is covered by 1e-6 (|o|_1 + |c|_1): the |c|_1 part is added to the half-extents here,
+// the |o|_1 part per ray.
 struct __attribute__((aligned(16))) DBvhNode {
     float cx, cy, cz, hmax;   // box centre; largest half-extent of a shape below this node
-    float hx, hy, hz, qa;     // box half-extents; max below of 2 (12 kF + 17) rho2^2
-    uint32_t skip;            // next node once this subtree is done or culled (DFS order: first child = this + 1)
-    uint32_t leaf;            // first * 32 + count: entries [first, first + count) of the leaf shape list; inner node: count == 0
-    float qb;                 // max below of 2 * 16 rho2 rhoF
-    float g0;                 // max below of 2 eps (6 kF + 7)
+    float hx, hy, hz, sa;     // box half-extents + 1e-6 |farthest corner|_1; sa (above)
+    uint32_t link;            // inner node: the next node once this subtree is done or culled, as a byte offset into the node
+                              // array (DFS order: first child = this + 1); leaf (the node after it is always the next one):
+                              // 0x80000000 | first * 32 + count: entries [first, first + count) of the leaf shape list
+    float sb, sg, c2x2;       // (above)
 };
 static_assert(sizeof(DBvhNode) == 48, "DBvhNode layout");
 
@@ -360,7 +371,7 @@ struct DBvh {
 // traversal instruction when every round waited for its slowest ray), so the throughput body lets the lanes whose
 // traversal has finished go on to shading and to their next ray while the others keep walking (bvh_advance's min_done).
 struct BvhTrav {
-    uint32_t i, i_end;        // next node of this ray's layout and the layout's end (i >= i_end: finished)
+    uint32_t i, i_end;        // next node of this ray's layout and the layout's end, as byte offsets into the node array (i >= i_end: finished)
     int best;                 // winner so far (-1 none) and its record, as the linear scan keeps them
     float best_t;
     Vec3 best_o, best_d;
@@ -429,8 +440,8 @@ __device__ __forceinline__ void bvh_begin(const DBvh B, const DScan* __restrict_
     }
     // this ray's near-to-far layout: nodes [i, i_end) of the concatenated array
     const uint32_t octant = B.by_octant ? ((rd.x < 0.0f ? 1u : 0u) | (rd.y < 0.0f ? 2u : 0u) | (rd.z < 0.0f ? 4u : 0u)) : 0u;
-    T.i_end = (octant + 1u) * B.n_nodes;
-    T.i = walk ? octant * B.n_nodes : T.i_end;
+    T.i_end = (octant + 1u) * B.n_nodes * (uint32_t)sizeof(DBvhNode);
+    T.i = walk ? octant * B.n_nodes * (uint32_t)sizeof(DBvhNode) : T.i_end;
     if (cached >= 0) bvh_test_shape<AFFINE>(scan, wrows, (uint32_t)cached, ro, rd, tmin, tmax, diag, T);
 }
 
@@ -444,59 +455,56 @@ __device__ __forceinline__ void bvh_advance(const DBvh B, const DScan* __restric
                                             Vec3 ro, Vec3 rd, float tmin, float tmax, const bool scene_diag, const bool lane_diag,
                                             const bool act, const uint32_t min_done, BvhTrav& T) {
     if (__ballot(act && T.i < T.i_end) == 0ull) return;
-    const float EPS = 5.9604645e-8f;
     const float big = 1.0e30f;
     const float idx = (__builtin_fabsf(rd.x) < 1.0e-30f) ? __builtin_copysignf(big, rd.x) : 1.0f / rd.x;
     const float idy = (__builtin_fabsf(rd.y) < 1.0e-30f) ? __builtin_copysignf(big, rd.y) : 1.0f / rd.y;
     const float idz = (__builtin_fabsf(rd.z) < 1.0e-30f) ? __builtin_copysignf(big, rd.z) : 1.0f / rd.z;
-    const float o2 = ro.x * ro.x + ro.y * ro.y + ro.z * ro.z;
-    const float o1 = __builtin_fabsf(ro.x) + __builtin_fabsf(ro.y) + __builtin_fabsf(ro.z);
+    // the slabs as (c -/+ e) * (1 / d) - o * (1 / d): the second product once per ray.  A ray for which it is not comfortably
+    // finite (origin beyond 1e8 with a direction component below 1e-22, ...) culls nothing
+    const float rix = ro.x * idx, riy = ro.y * idy, riz = ro.z * idz;
+    const bool wide = !((__builtin_fabsf(rix) < big) && (__builtin_fabsf(riy) < big) && (__builtin_fabsf(riz) < big));
+    const float o2x2 = 2.0f * (ro.x * ro.x + ro.y * ro.y + ro.z * ro.z);
+    const float o1e = 1.0e-6f * (__builtin_fabsf(ro.x) + __builtin_fabsf(ro.y) + __builtin_fabsf(ro.z));
     for (;;) {
       uint32_t leaf_first = 0, leaf_count = 0;
       uint32_t i = T.i;
       const uint32_t i_end = act ? T.i_end : 0u;
-      const int best = T.best;
-      const float best_t = T.best_t;
+      // a node that starts beyond the best hit so far (or beyond tmax) is culled; best only changes between the inner loops
+      const float tlim = (T.best >= 0) ? __builtin_fminf(tmax, T.best_t) : tmax;
       while (i < i_end) {
         // the conservative node test is this library's own arithmetic, not the reference's: fused multiply-adds are welcome
         // (every bound below carries a relative margin far above one rounding)
 #pragma clang fp contract(fast)
-        const float4* np = reinterpret_cast<const float4*>(B.nodes + i);
+        const float4* np = reinterpret_cast<const float4*>(reinterpret_cast<const unsigned char*>(B.nodes) + i);
         const float4 n0 = np[0], n1 = np[1], n2 = np[2];
-        // D: distance to the farthest corner of the box; (|o| + |c|)^2 <= 2 |o|^2 + 2 |c|^2 with c its farthest corner
-        // from the world origin; both squared sums padded by 1e-5 for their own rounding
+        // D: distance to the farthest corner of the (padded) box
         const float fx = __builtin_fabsf(ro.x - n0.x) + n1.x, fy = __builtin_fabsf(ro.y - n0.y) + n1.y, fz = __builtin_fabsf(ro.z - n0.z) + n1.z;
-        const float gx = __builtin_fabsf(n0.x) + n1.x, gy = __builtin_fabsf(n0.y) + n1.y, gz = __builtin_fabsf(n0.z) + n1.z;
-        const float D2 = (fx * fx + fy * fy + fz * fz) * 1.00001f;
-        const float W2 = 2.0f * (o2 + gx * gx + gy * gy + gz * gz) * 1.00001f;
-        const float W = o1 + gx + gy + gz;                       // an upper bound of |o| + |c| for the slab padding
-        const float S = EPS * (n1.w * D2 + n2.z * __builtin_amdgcn_sqrtf(D2 * W2) * 1.01f) + n2.w;
-        // sqrt(1 + S) - 1 <= min(S, sqrt(S)); the v_sqrt_f32 estimate is padded by 1 %
-        const float grow = (S < 1.0f) ? S : __builtin_amdgcn_sqrtf(S) * 1.01f;
+        const float D2 = fx * fx + fy * fy + fz * fz;
+        const float DW = __builtin_amdgcn_sqrtf(D2 * (o2x2 + n2.w));
+        const float S2 = n1.w * D2 + (n2.y * DW + n2.z);                                     // S / 2
+        const float grow = __builtin_fminf(S2, __builtin_amdgcn_sqrtf(S2) * 1.4285f);         // sqrt(S) = sqrt(2) sqrt(S / 2), the estimate padded by 1 %
 #ifdef RT_BVH_NO_MARGIN   // experiment: how many reference hits a geometric (unpadded) hierarchy would lose
         const float e = 0.0f * grow;
 #else
-        const float e = n0.w * grow + 1.0e-6f * W;
+        const float e = n0.w * grow + o1e;
 #endif
         const float ex = n1.x + e, ey = n1.y + e, ez = n1.z + e;
-        const float ax = (n0.x - ex - ro.x) * idx, bx = (n0.x + ex - ro.x) * idx;
-        const float ay = (n0.y - ey - ro.y) * idy, by = (n0.y + ey - ro.y) * idy;
-        const float az = (n0.z - ez - ro.z) * idz, bz = (n0.z + ez - ro.z) * idz;
+        const float ax = (n0.x - ex) * idx - rix, bx = (n0.x + ex) * idx - rix;
+        const float ay = (n0.y - ey) * idy - riy, by = (n0.y + ey) * idy - riy;
+        const float az = (n0.z - ez) * idz - riz, bz = (n0.z + ez) * idz - riz;
         const float tn = __builtin_fmaxf(__builtin_fmaxf(__builtin_fminf(ax, bx), __builtin_fminf(ay, by)), __builtin_fminf(az, bz));
         const float tf = __builtin_fminf(__builtin_fminf(__builtin_fmaxf(ax, bx), __builtin_fmaxf(ay, by)), __builtin_fmaxf(az, bz));
         const float slack = 1.0e-3f * __builtin_fabsf(tn) + 1.0e-4f;
-        bool pass = (tn <= tf) && (tf + 1.0e-3f * __builtin_fabsf(tf) + 1.0e-4f >= tmin) && (tn - slack <= tmax);
-        if (best >= 0 && tn - slack > best_t) pass = false;
-        const uint32_t skip = __float_as_uint(n2.x), first = __float_as_uint(n2.y) >> 5, count = __float_as_uint(n2.y) & 31u;
-        if (pass) {
-            i = i + 1u;
-            if (count != 0u) {
-                leaf_first = first;
-                leaf_count = count;
-                break;
-            }
-        } else {
-            i = skip;
+        // (no short-circuit: three compares and their conjunction cost less than the branches around them)
+        const bool p_order = tn <= tf, p_near = tf + 1.0e-3f * __builtin_fabsf(tf) + 1.0e-4f >= tmin, p_far = tn - slack <= tlim;
+        const bool pass = (p_order & p_near & p_far) | wide;
+        const uint32_t link = __float_as_uint(n2.x);
+        const bool is_leaf = (int)link < 0;
+        i = (pass | is_leaf) ? i + (uint32_t)sizeof(DBvhNode) : link;
+        if (pass & is_leaf) {
+            leaf_first = (link & 0x7FFFFFFFu) >> 5;
+            leaf_count = link & 31u;
+            break;
         }
       }
       if (act) T.i = i;
