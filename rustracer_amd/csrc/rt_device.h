@@ -27,7 +27,7 @@ struct __attribute__((aligned(16))) DScan {
     uint32_t kind;      // RT_SHAPE_*
     uint32_t material;  // index into the material table (the shape index when staged in LDS)
     uint32_t needs_uv;  // 1 if either pigment of the material reads (u,v)
-    uint32_t pad;
+    uint32_t shape;     // the hierarchy's leaf records (a copy of this table in leaf order): the shape's index in the World
 };
 static_assert(sizeof(DScan) == 64, "DScan layout");
 // Transformation.m rows 0..2 (48 B), read per lane once per ray for the winner.
@@ -360,7 +360,8 @@ static_assert(sizeof(DBvhNode) == 48, "DBvhNode layout");
 
 struct DBvh {
     const DBvhNode* nodes;       // n_nodes, or 8 * n_nodes: the tree laid out once per sign octant of the ray direction (near half first)
-    const uint32_t* leaf_shapes;
+    const DScan* leaf_scan;      // the scan records of the bounded shapes in leaf order (DScan.shape: the shape's index): a leaf's
+                                 // tests read consecutive records, no index list in between
     const uint32_t* unbounded;   // shapes outside the hierarchy, ascending
     uint32_t n_nodes, n_unbounded;
     uint32_t by_octant;          // 1: `nodes` holds the 8 layouts; 0: one layout (small trees: 8 copies would only thrash the L1)
@@ -380,10 +381,10 @@ struct BvhTrav {
 
 // one shape's own test; the winner is the minimum by (t, index).  `diag` is wave-uniform.
 template <bool AFFINE>
-__device__ __forceinline__ void bvh_test_shape(const DScan* __restrict__ scan, const DWRows* __restrict__ wrows, uint32_t i,
-                                               Vec3 ro, Vec3 rd, float tmin, float tmax, bool diag, BvhTrav& T) {
-    const Rows3 R = load_rows(scan[i].inv);
-    const uint32_t kind = scan[i].kind;
+__device__ __forceinline__ void bvh_test_record(const DScan* __restrict__ S, const DWRows* __restrict__ wrows, uint32_t i,
+                                                Vec3 ro, Vec3 rd, float tmin, float tmax, bool diag, BvhTrav& T) {
+    const Rows3 R = load_rows(S->inv);
+    const uint32_t kind = S->kind;
     Vec3 o, d;
     if (AFFINE && diag) {
         o = rows_point_diag(R, ro.x, ro.y, ro.z);
@@ -403,6 +404,12 @@ __device__ __forceinline__ void bvh_test_shape(const DScan* __restrict__ scan, c
         T.best_d = d;
         T.best_kind = kind;
     }
+}
+
+template <bool AFFINE>
+__device__ __forceinline__ void bvh_test_shape(const DScan* __restrict__ scan, const DWRows* __restrict__ wrows, uint32_t i,
+                                               Vec3 ro, Vec3 rd, float tmin, float tmax, bool diag, BvhTrav& T) {
+    bvh_test_record<AFFINE>(scan + i, wrows, i, ro, rd, tmin, tmax, diag, T);
 }
 
 // Start a ray (every ACTIVE lane starts one; call it inside the branch of the starting lanes): the unbounded shapes,
@@ -511,7 +518,10 @@ __device__ __forceinline__ void bvh_advance(const DBvh B, const DScan* __restric
       const unsigned long long at_leaf = __ballot(leaf_count != 0u);
       if (at_leaf == 0ull) break;
       const bool diag = AFFINE && scene_diag && __ballot(leaf_count != 0u && !lane_diag) == 0ull;
-      for (uint32_t k = 0; k < leaf_count; ++k) bvh_test_shape<AFFINE>(scan, wrows, B.leaf_shapes[leaf_first + k], ro, rd, tmin, tmax, diag, T);
+      for (uint32_t k = 0; k < leaf_count; ++k) {
+          const DScan* S = B.leaf_scan + leaf_first + k;
+          bvh_test_record<AFFINE>(S, wrows, S->shape, ro, rd, tmin, tmax, diag, T);
+      }
       if ((uint32_t)__popcll(__ballot(act && T.i >= T.i_end)) >= min_done) break;
     }
 }
