@@ -834,6 +834,15 @@ def main():
             out["strong"] = strong
         if call:
             out["call"] = call
+            if achieved is not None:
+                # the same algorithmic flops over ONE frame: as the rt_fire_all_rays call delivers them (H2D, render, D2H: the
+                # number SURVEY section 8(d) defines) and as a lone resident frame's kernel does -- beside `frac`, which is the
+                # multi-frame launch
+                one = my_rays_per_frame * fpr / 1e12
+                one_exec = (my_rays_per_frame - my_shared_per_frame) * fpr / 1e12
+                out["roofline"]["frac_single_call"] = one / (call["call_ms"] * 1e-3) / PEAK_FP32_VECTOR_TFLOPS
+                out["roofline"]["frac_single_frame_resident"] = one / (call["frame_ms_resident"] * 1e-3) / PEAK_FP32_VECTOR_TFLOPS
+                out["roofline"]["frac_single_call_executed"] = one_exec / (call["call_ms"] * 1e-3) / PEAK_FP32_VECTOR_TFLOPS
         if not D and not args.no_cpu_baseline and c3:
             out["cpu_baseline"], outl = cpu_baseline(flat, cam, rr, WIDTH, HEIGHT, AA, gpu_frame)
             if outl:
