@@ -353,7 +353,7 @@ struct __attribute__((aligned(16))) DBvhNode {
     float hx, hy, hz, sa;     // box half-extents + 1e-6 |farthest corner|_1; sa (above)
     uint32_t link;            // inner node: the next node once this subtree is done or culled, as a byte offset into the node
                               // array (DFS order: first child = this + 1); leaf (the node after it is always the next one):
-                              // 0x80000000 | first * 32 + count: entries [first, first + count) of the leaf shape list
+                              // 0x80000000 | first * 32 + count: entries [first, first + count) of the leaf records (DBvh.leaf_scan)
     float sb, sg, c2x2;       // (above)
 };
 static_assert(sizeof(DBvhNode) == 48, "DBvhNode layout");
