@@ -81,3 +81,27 @@ def test_direct_stores_fall_back_to_copies_when_the_probe_fails():
     assert r.returncode == 0, r.stderr[-2000:]
     assert "remote-store probe exited 9" in r.stderr, r.stderr[-2000:]
     assert "verify ok" in r.stderr and "p2p copies in place" in r.stderr, r.stderr[-2000:]
+
+
+def test_one_gpu_bench_line_carries_the_contract():
+    """`python bench.py --gpus 1 --steps K --warmup W` prints ONE JSON line with the contract's keys, the roofline object
+    (incl. the single-call fractions beside the multi-frame one) and the CPU baseline beside it."""
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "4", "--warmup", "1", "--repeats", "2"],
+                       cwd=ROOT, env=env, capture_output=True, text=True, timeout=280)
+    assert p.returncode == 0, p.stderr[-2000:]
+    lines = [l for l in p.stdout.splitlines() if l.strip()]
+    assert len(lines) == 1, lines
+    d = json.loads(lines[0])
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
+              "dtype", "data", "config", "roofline", "cpu_baseline", "call"):
+        assert k in d, k
+    assert d["n_gpus"] == 1 and d["steps"] == 4 and d["warmup"] == 1 and d["unit"] == "path samples/s" and d["dtype"] == "f32"
+    assert d["vs_baseline"] is None and d["higher_is_better"] is True and "workload" in d["config"]
+    r = d["roofline"]
+    assert r["bound"] == "valu" and r["unit"] == "TFLOP/s" and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-12
+    assert r["traffic"] is None or r["traffic"] > 0
+    assert 0 < r["frac_single_call"] < r["frac_single_frame_resident"] < r["frac"]
+    assert abs(d["value"] - 1920 * 1080 * 4 / (d["ms_per_step"] * 4e-3)) / d["value"] < 1e-6
+    c = d["cpu_baseline"]
+    assert c["kind"] == "port" and c["cores"] >= 1 and c["value"] > 0 and c["unit"] == d["unit"] and c["sample"]
