@@ -364,6 +364,7 @@ struct DBvh {
                                  // tests read consecutive records, no index list in between
     const uint32_t* unbounded;   // shapes outside the hierarchy, ascending
     uint32_t n_nodes, n_unbounded;
+    uint32_t n_leaf;             // records of leaf_scan
     uint32_t by_octant;          // 1: `nodes` holds the 8 layouts; 0: one layout (small trees: 8 copies would only thrash the L1)
 };
 

@@ -367,7 +367,7 @@ struct NodeOut {
 #else
 #define K_DEBUG (FAST ? (unsigned long long*)nullptr : P.debug_waves)
 #endif
-template <bool AFFINE, bool STACK_LDS, bool SCENE_LDS, bool TEAMS, int FAST>
+template <bool AFFINE, bool STACK_LDS, bool SCENE_LDS, bool TEAMS, int FAST, bool BVH_LDS = false>
 __global__ __launch_bounds__(RT_BLOCK, RT_WAVES_PER_EU) void k_pass(const PassParams P, const DScan* __restrict__ g_scan,
                                                    const DMRows* __restrict__ g_mrows,
                                                    const DWRows* __restrict__ g_wrows,
@@ -419,6 +419,18 @@ __global__ __launch_bounds__(RT_BLOCK, RT_WAVES_PER_EU) void k_pass(const PassPa
     DShade* lds_shade = reinterpret_cast<DShade*>(lds_mrows + n_staged);
     DMaterial* lds_mats = reinterpret_cast<DMaterial*>(lds_shade + n_staged);
     float4* lds_stack = reinterpret_cast<float4*>(lds_mats + n_staged);
+    // BVH_LDS: the hierarchy's nodes and leaf records instead (the recursion stack is in HBM then)
+    static_assert(!BVH_LDS || (FAST == 1 && !SCENE_LDS && !STACK_LDS && !TEAMS), "the LDS hierarchy serves the plain throughput body");
+    DBvhNode* lds_nodes = reinterpret_cast<DBvhNode*>(lds_scan);
+    DScan* lds_leaf = reinterpret_cast<DScan*>(lds_nodes + (BVH_LDS ? P.bvh.n_nodes : 0u));
+    if (BVH_LDS) {
+        uint32_t* dst_n = reinterpret_cast<uint32_t*>(lds_nodes);
+        const uint32_t* src_n = reinterpret_cast<const uint32_t*>(P.bvh.nodes);
+        for (uint32_t i = tid; i < P.bvh.n_nodes * (uint32_t)(sizeof(DBvhNode) / 4); i += RT_BLOCK) dst_n[i] = src_n[i];
+        uint32_t* dst_l = reinterpret_cast<uint32_t*>(lds_leaf);
+        const uint32_t* src_l = reinterpret_cast<const uint32_t*>(P.bvh.leaf_scan);
+        for (uint32_t i = tid; i < P.bvh.n_leaf * (uint32_t)(sizeof(DScan) / 4); i += RT_BLOCK) dst_l[i] = src_l[i];
+    }
     if (TEAMS) {
         const uint32_t* src = reinterpret_cast<const uint32_t*>(C0->tables);
         uint32_t* dst = reinterpret_cast<uint32_t*>(lds_tab);
@@ -588,6 +600,12 @@ __global__ __launch_bounds__(RT_BLOCK, RT_WAVES_PER_EU) void k_pass(const PassPa
             if (P.bvh.n_nodes != 0u) {
                 // image renders trace with tmin 1e-5 / 1e-3 (>= 0, as the sparse form's proof needs); batch solves bring their own
                 const bool dg = AFFINE && P.scene_diag != 0u && K_MODE == 0u && __ballot(!diag_ray_ok(o, d)) == 0ull;
+                if constexpr (BVH_LDS) {
+                    DBvh Bl = P.bvh;
+                    Bl.nodes = lds_nodes;
+                    Bl.leaf_scan = lds_leaf;
+                    return bvh_closest_hit<AFFINE>(Bl, g_scan, g_wrows, P.n_shapes, o, d, tmin, tmax, t, lo, ld, bkind, dg, cached);
+                }
                 return bvh_closest_hit<AFFINE>(P.bvh, g_scan, g_wrows, P.n_shapes, o, d, tmin, tmax, t, lo, ld, bkind, dg, cached);
             }
         }
